@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Headline benchmark: CycleGAN train steps/sec on 132^3 x 1 volumes (BASELINE.json config[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+
+A "step" is one EM2EM.train_step (6 generator forwards, 4 discriminator forwards, 10 loss
+terms, all input/kernel gradients, gradient all-reduce for N > 1, 4 Adam updates) on
+synthetic uint8-derived volumes already resident in HBM.  N > 1 is launched by
+torch.distributed.run with one process per GPU (RCCL); per-GPU batch is fixed (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+RIDGE = FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+
+def synthetic_volume(shape, seed):
+    """SURVEY 8(d) distribution U: uint8 uniform, scaled x/127.5-1 then standardized (datasets.py:157-202)."""
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, 256, shape, dtype=np.uint8)
+    x = u.astype(np.float32) / np.float32(127.5) - np.float32(1.0)
+    return ((x - x.mean()) / x.std()).astype(np.float32)[..., None]
+
+
+def per_kernel_profile(model, st, steps):
+    """Time every launch of the step with HIP events on the launch stream; aggregate by kernel symbol."""
+    from transfer_em_amd import hip_ops as H
+    s = H.current_stream()
+    agg = {}
+    for _ in range(steps):
+        st.losses.zero_()
+        evs = []
+        for l in st.compute + st.update:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); l(s); b.record()
+            evs.append((l, a, b))
+        torch.cuda.synchronize()
+        for l, a, b in evs:
+            k = l.meta.get("kernel", l.name.split(".")[0] + ".misc")
+            d = agg.setdefault(k, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            d["ms"] += a.elapsed_time(b); d["launches"] += 1
+            d["flops"] += l.meta.get("flops", 0.0); d["bytes"] += l.meta.get("bytes", 0.0)
+    return agg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
+    ap.add_argument("--dimsize", type=int, default=132)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dist = world > 1
+    if dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from transfer_em_amd.cgan import EM2EM
+    n, B = args.dimsize, args.batch
+    model = EM2EM(n, "bench", is3d=True, seed=42, checkpoint_root=os.path.join("/tmp", f"tem_bench_{os.getpid()}"))
+    shape = (B, n, n, n)
+    rx = torch.from_numpy(synthetic_volume(shape, 1234 + rank)).cuda()
+    ry = torch.from_numpy(synthetic_volume(shape, 5678 + rank)).cuda()
+
+    def barrier():
+        if dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step(rx, ry)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = model.train_step(rx, ry)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = losses.cpu().numpy()
+    assert np.isfinite(losses).all(), losses
+
+    out = None
+    if rank == 0:
+        st = model._steps[B]
+        agg = per_kernel_profile(model, st, max(2, min(5, args.steps)))
+        dom_k, dom = max(((k, v) for k, v in agg.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
+        secs = dom["ms"] * 1e-3
+        ai = dom["flops"] / dom["bytes"]
+        if ai > RIDGE:
+            roof = dict(bound="mfma", achieved=dom["flops"] / secs / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s")
+        else:
+            roof = dict(bound="hbm", achieved=dom["bytes"] / secs / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["kernel"] = dom_k
+        roof["avg_launch_us"] = dom["ms"] * 1e3 / dom["launches"]
+        roof["share_of_step"] = dom["ms"] / sum(v["ms"] for v in agg.values())
+        tot_flops = sum(v["flops"] for v in agg.values()) / max(2, min(5, args.steps))
+        tot_bytes = sum(v["bytes"] for v in agg.values()) / max(2, min(5, args.steps))
+        if args.kernel_table:
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+                s_ = v["ms"] * 1e-3
+                print(f"{k:48s} {v['launches']:5d} launches {v['ms']:9.3f} ms  "
+                      f"{v['flops'] / s_ / 1e12 if s_ else 0:7.2f} TFLOP/s {v['bytes'] / s_ / 1e9 if s_ else 0:8.1f} GB/s",
+                      file=sys.stderr)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle.torch_ref import TimedBaseline
+            cores = os.cpu_count() or 1
+            base = TimedBaseline(n, batch=B, is3d=True, threads=cores)
+            cx, cy = rx.cpu().permute(0, 4, 1, 2, 3).contiguous(), ry.cpu().permute(0, 4, 1, 2, 3).contiguous()
+            base.step(cx, cy)                                  # warm-up (oneDNN primitive creation)
+            c0 = time.perf_counter()
+            base.step(cx, cy)
+            cdt = time.perf_counter() - c0
+            cpu = dict(value=1.0 / cdt, unit="steps/s", cores=cores, kind="port",
+                       sample=f"1 warm-up + 1 timed train step, 3D {n}^3 batch {B} fp32, oracle/torch_ref.py "
+                              "(PyTorch-CPU/oneDNN restatement of cgan.py:144-230; TF2 itself is not installable here)")
+        steps_per_s = args.steps * world / dt
+        out = {
+            "metric": "CycleGAN train steps/sec on 132^3 x1 uint8 volumes (per-GPU batch of 1 volume; aggregate over GPUs)",
+            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3D {n}^3 single-channel synthetic volumes, batch={B} per GPU, fp32, "
+                                   f"EM2EM.train_step (BASELINE.json configs[1])",
+                       "global_batch": B * world, "dimsize": n, "parallelism": f"dp{world}",
+                       "volumes_per_s": steps_per_s * B,
+                       "algorithmic_gflop_per_step": tot_flops / 1e9, "algorithmic_gb_per_step": tot_bytes / 1e9},
+            "roofline": roof, "cpu_baseline": cpu,
+            "losses": [float(v) for v in losses],
+        }
+        print(json.dumps(out), flush=True)
+    if dist:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,205 @@
+/*
+ * tem_hip.h -- C ABI of libtem_hip.so, the MI355X (gfx950) implementation of the
+ * arithmetic that transfer_em's CycleGAN hot path delegates to TensorFlow.
+ *
+ * The reference (janelia-flyem/transfer_em) has no FFI of its own: its hot path is
+ * Python calling tf.keras layers.  Each entry point below replaces
+ * the TF kernels behind the cited reference call sites (paths relative to the
+ * reference root).  Conventions for every function:
+ *
+ *   - plain C types only; all pointers are DEVICE pointers owned by the caller;
+ *   - activations are float32, channels-last (N,D,H,W,C); 2-D data is D == 1, kd == 1;
+ *   - work is enqueued on `stream` (a hipStream_t); nothing allocates, frees or
+ *     synchronises, so every call can be captured into a hipGraph;
+ *   - returns 0 on success, a negative TEM_E* code for a rejected argument, or a
+ *     positive hipError_t from the launch.
+ *
+ * INTEGRATION.md shows the ctypes binding the reference-side Python would add.
+ */
+#ifndef TEM_HIP_H
+#define TEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEM_ABI_VERSION 1
+
+#define TEM_OK            0
+#define TEM_EINVAL       -1   /* malformed descriptor (NULL pointer, negative dim, ...) */
+#define TEM_EUNSUPPORTED -2   /* channel count / kernel size outside the compiled set   */
+#define TEM_ESHAPE       -3   /* tensor extents inconsistent with the operator geometry  */
+
+typedef void *tem_stream_t;   /* hipStream_t */
+
+/* Strided view of a float32 NDHWC tensor.  Strides are in elements; the channel
+ * stride is 1.  A crop is a view (ptr offset + parent strides); a channel slice is
+ * a view with C smaller than sW. */
+typedef struct tem_view {
+  float  *ptr;
+  int32_t N, D, H, W, C;
+  int64_t sN, sD, sH, sW;
+} tem_view;
+
+/* Fused epilogue shared by the convolution entry points.  With acc the convolution
+ * result for one output element of out0 (bias already added):
+ *
+ *     v = acc + add[element - add_off]        (if add.ptr; zero outside add's window)
+ *     v = gate > 0 ? v : gate_slope * v       (if gate.ptr: LeakyReLU *gradient*,
+ *                                              gated on the saved forward output)
+ *     v = keep(element) ? 2 v : 0             (if dropout: Philox4x32-10 stream
+ *                                              (seed, site, step); element = dense
+ *                                              NDHWC index in out0)
+ *     v = v > 0 ? v : slope * v               (forward LeakyReLU; slope 1 = linear)
+ *
+ * Channels written to out1 (the second half of a split output) skip add/gate/
+ * dropout/slope and receive the raw accumulator.
+ *
+ * Replaces: tf.keras.layers.LeakyReLU (models/utils.py:77,83,126,135;
+ * generator.py:57,99,109; discriminator.py:53,74,94), Dropout(0.5)
+ * (models/utils.py:134) and their gradients, Cropping/Concatenate gradients
+ * (generator.py:74-86).
+ */
+typedef struct tem_epilogue {
+  const float *bias;          /* [C_out] or NULL (discriminator.py:97-99 only)        */
+  float        slope;
+  tem_view     gate;          /* same extents as out0, or ptr == NULL                 */
+  float        gate_slope;
+  tem_view     add;           /* window placed at add_off inside out0, or ptr == NULL */
+  int32_t      add_off[3];
+  int32_t      dropout;       /* 0 / 1                                                */
+  uint64_t     seed;
+  uint32_t     site;
+  uint32_t     step;
+  const uint32_t *step_dev;   /* if non-NULL the step is read from device memory
+                                 (graph replay) and `step` is ignored               */
+} tem_epilogue;
+
+/* Weight addressing for tem_conv: element (tap, c_in, c_out) of the operator's
+ * kernel is w[tap' * C_a * C_b + ...] with
+ *   TEM_W_TAP_CI_CO : w[tap][c_in][c_out]                  (Keras Conv kernel, forward;
+ *                                                           Keras ConvTranspose kernel
+ *                                                           used as its own input-grad)
+ *   TEM_W_FLIP_CO_CI: w[ntap-1-tap][c_out][c_in]           (input-gradient of a
+ *                                                           stride-1 Keras Conv)       */
+#define TEM_W_TAP_CI_CO  0
+#define TEM_W_FLIP_CO_CI 1
+
+typedef struct tem_conv_args {
+  tem_view in0, in1;          /* logical input = concat(in0, in1) on C; in1.ptr may be NULL */
+  const float *w;
+  int32_t w_layout;
+  int32_t kd, kh, kw;         /* kernel extents, each in {1,3,4}                       */
+  int32_t sd, sh, sw;         /* strides, each in {1,2}                                */
+  int32_t pd, ph, pw;         /* zero padding; negative == crop                        */
+  tem_view out0, out1;        /* output channels [0,out0.C) and [out0.C, out0.C+out1.C) */
+  tem_epilogue ep;
+} tem_conv_args;
+
+/* out[n,o,co] = sum_{tap,ci} in[n, o*s + tap - p, ci] * W(tap,ci,co)   (cross-correlation)
+ *
+ * Replaces the TF kernels behind tf.keras.layers.Conv2D/Conv3D forward
+ * (models/utils.py:73,80,122; generator.py:54,96,108,110; discriminator.py:45,78,97),
+ * Conv3DBackpropInput for the stride-1 layers (TEM_W_FLIP_CO_CI, p = k-1-p_fwd), and
+ * Conv3DTranspose's input-gradient (a stride-2 convolution, models/utils.py:129). */
+int tem_conv(const tem_conv_args *a, tem_stream_t stream);
+
+/* out[n,o,co] = sum over (j,tap) with o == j*s + tap - p of in[n,j,ci] * w[tap][co][ci]
+ *
+ * Replaces tf.keras.layers.Conv3DTranspose forward (models/utils.py:129-130; 'same'
+ * padding with k 4, s 2 is p = 1) and Conv3DBackpropInput of the stride-2 layers
+ * (models/utils.py:80; p = 0, Keras kernel (tap,C_in,C_out) read as [tap][co][ci]).
+ * w_layout is ignored. */
+int tem_conv_transpose(const tem_conv_args *a, tem_stream_t stream);
+
+/* The shape-generic VALU implementations behind tem_conv / tem_conv_transpose, exported so
+ * that tests can compare them with the LDS/MFMA-tiled kernels the dispatcher prefers. */
+int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream);
+int tem_conv_transpose_direct(const tem_conv_args *a, tem_stream_t stream);
+
+typedef struct tem_bww_args {
+  tem_view in0, in1;          /* forward input (concat on C)                           */
+  tem_view dout;              /* gradient w.r.t. the pre-activation output             */
+  int32_t kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  float  *slabs;              /* partial sums: slab s starts at slabs + s*slab_stride   */
+  int64_t slab_stride;        /* elements between slabs; 0 == ntap*C_in*C_out (dense).
+                                 A whole network shares one [nslab][n_params] workspace
+                                 by passing slabs = ws + param_offset, stride = n_params */
+  int32_t nslab;              /* number of partial slabs the voxel range is split into */
+  int32_t accumulate;         /* 0: slabs are overwritten, 1: added to                 */
+} tem_bww_args;
+
+/* slab[s][tap][ci][co] (+)= sum over the s-th share of (n,o) of
+ *                           in[n, o*s + tap - p, ci] * dout[n, o, co]
+ *
+ * Replaces Conv3DBackpropFilter (all Conv layers) and, with in := upstream gradient
+ * and dout := the layer input, the kernel gradient of Conv3DTranspose in its Keras
+ * layout (tap, C_out, C_in).  The split over slabs is deterministic; tem_reduce_slabs
+ * finishes the sum. */
+int tem_conv_bwd_weight(const tem_bww_args *a, tem_stream_t stream);
+
+/* out[i] = (accumulate ? out[i] : 0) + scale * sum_s slabs[s*slab_stride + i]
+ * (slab_stride 0 == n) */
+int tem_reduce_slabs(const float *slabs, int32_t nslab, int64_t n, int64_t slab_stride,
+                     float *out, int32_t accumulate, float scale, tem_stream_t stream);
+
+/* out[c] = (accumulate ? out[c] : 0) + sum over all (n,d,h,w) of g[...,c]   (bias gradient,
+ * discriminator.py:97-99) */
+int tem_channel_sum(const tem_view *g, float *out, int32_t accumulate, tem_stream_t stream);
+
+/* tfa.losses.SigmoidFocalCrossEntropy(from_logits=True, alpha=0.5, gamma) with
+ * Reduction.AUTO, as used by generator_loss / discriminator_loss (cgan.py:78-79,110-120).
+ *   L = mean over z of 0.5 * (1-p_t)^gamma * BCEWithLogits(target, z)
+ * losses[k] += loss_scale * L for every bit k set in slot_mask (losses is double[8]);
+ * if dz.ptr: dz = grad_scale * dL/dz. */
+int tem_focal_logits(const tem_view *z, int32_t target, float gamma,
+                     double *losses, uint32_t slot_mask, float loss_scale,
+                     const tem_view *dz, float grad_scale, tem_stream_t stream);
+
+/* identity_loss / calc_cycle_loss (cgan.py:122-142): t = 1 - |a-b|/2,
+ *   L = mean of 0.5 * (1-t)^gamma * -log(clip(t,eps,1-eps)+eps)   (from_logits=False form)
+ * losses[k] += loss_scale * L; if db.ptr: db = grad_scale * dL/db (db has b's extents). */
+int tem_focal_match(const tem_view *a, const tem_view *b, float gamma,
+                    double *losses, uint32_t slot_mask, float loss_scale,
+                    const tem_view *db, float grad_scale, tem_stream_t stream);
+
+/* tf.keras.optimizers.Adam dense update (cgan.py:69-73,218-228), Keras/TF2 form:
+ *   t = *step_dev + 1;  lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  theta -= lr_t * m / (sqrt(v) + eps)
+ * g = grad_scale * grad.  step_dev is NOT incremented here (see tem_step_tick). */
+int tem_adam_keras(float *theta, const float *grad, float *m, float *v, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float grad_scale,
+                   const uint32_t *step_dev, tem_stream_t stream);
+
+/* *step_dev += 1 (one thread). */
+int tem_step_tick(uint32_t *step_dev, tem_stream_t stream);
+
+/* datasets.py:193-202 + 157-163: out = ((float)in / 127.5 - 1 - mean) / std */
+int tem_u8_to_f32_std(const uint8_t *in, float *out, int64_t n, float mean, float std,
+                      tem_stream_t stream);
+
+/* utils.py:109,118: out = (uint8) rint((y*std + mean + 1) * 127.5)  (wraps mod 256).
+ * `y` is a view (tile interior), `out` a dense-by-strides uint8 block with element
+ * strides oD,oH,oW (batch 1, channel 0). */
+int tem_f32_unstd_to_u8(const tem_view *y, uint8_t *out, int64_t oD, int64_t oH, int64_t oW,
+                        float mean, float std, tem_stream_t stream);
+
+/* dst[i] = value */
+int tem_fill_f32(float *dst, int64_t n, float value, tem_stream_t stream);
+
+/* dst(view) = src(view) elementwise; same extents (crop / pad / channel-slice copies) */
+int tem_copy_view(const tem_view *src, const tem_view *dst, tem_stream_t stream);
+
+/* dst(view) += src(view) */
+int tem_add_view(const tem_view *src, const tem_view *dst, tem_stream_t stream);
+
+/* Library identification: returns TEM_ABI_VERSION; *arch (if non-NULL) receives a
+ * static string naming the compiled offload target ("gfx950"). */
+int tem_abi_version(const char **arch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEM_HIP_H */

@@ -1,0 +1,248 @@
+"""Operator-level parity: every C-ABI convolution entry point vs the CPU oracle.
+
+Bar: |hip - oracle|_max <= 2e-5 * |oracle|_max (fp32 fmaf chains vs the oracle's double
+accumulation; north_star's bar is 1e-3 relative).  Each case is one geometry the hot path uses.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    from transfer_em_amd import hip_ops
+    hip_ops.require_gpu()
+    return hip_ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rnd(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+FWD_CASES = [  # (CI, CO, k, s, pad, edge, is3d)
+    (1, 8, 3, 1, 0, 20, True), (8, 8, 3, 1, 0, 18, True), (8, 8, 4, 2, 0, 18, True), (8, 16, 3, 1, 0, 12, True),
+    (16, 16, 4, 2, 0, 13, True), (16, 32, 3, 1, 0, 9, True), (32, 32, 3, 1, 0, 9, True), (32, 16, 3, 1, 0, 9, True),
+    (16, 16, 3, 1, 0, 11, True), (16, 1, 3, 1, 0, 14, True), (32, 32, 1, 1, 0, 5, True), (32, 1, 1, 1, 0, 5, True),
+    (32, 32, 4, 2, 0, 10, True), (1, 8, 3, 1, 5, 10, True), (1, 16, 3, 1, 0, 30, False), (16, 32, 3, 1, 0, 20, False),
+    (32, 32, 4, 2, 0, 21, False),
+]
+
+
+@pytest.mark.parametrize("CI,CO,k,s,pad,n,is3d", FWD_CASES)
+@pytest.mark.parametrize("direct", [False, True])
+def test_conv_forward(H, oracle_lib, CI, CO, k, s, pad, n, is3d, direct):
+    rng = np.random.default_rng(CI * 1000 + CO * 10 + k)
+    D = n if is3d else 1
+    kd = k if is3d else 1
+    x = rnd(rng, 2, D, n, n + 1, CI)
+    w = rnd(rng, kd, k, k, CI, CO) * 0.2
+    bias = rnd(rng, CO) if CO == 1 else None
+    st, pd = ((s,) * 3, (pad,) * 3) if is3d else ((1, s, s), (0, pad, pad))
+    ref = oracle_lib.leaky_relu(oracle_lib.conv_fwd(x, w, st, pd, bias))
+    out = torch.empty(ref.shape, dtype=torch.float32, device="cuda")
+    wd = dev(w.reshape(-1))
+    H.run([H.conv_launch("t", dev(x), wd, out, k, s, pad, is3d=is3d, slope=0.3,
+                         bias=dev(bias) if bias is not None else None, direct=direct)])
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+def test_conv_concat_and_crop_views(H, oracle_lib):
+    """Fused Concatenate([up, Cropping3D(skip)]) on the consumer's loads (generator.py:74-86,92)."""
+    rng = np.random.default_rng(7)
+    up = rnd(rng, 1, 10, 10, 10, 8)
+    skip = rnd(rng, 1, 15, 15, 15, 8)            # odd difference: crop 2 low / 3 high
+    w = rnd(rng, 3, 3, 3, 16, 16) * 0.1
+    cat = np.concatenate([up, skip[:, 2:12, 2:12, 2:12, :]], -1)
+    ref = oracle_lib.leaky_relu(oracle_lib.conv_fwd(cat, w))
+    out = torch.empty(ref.shape, dtype=torch.float32, device="cuda")
+    sk = dev(skip)
+    H.run([H.conv_launch("t", dev(up), dev(w.reshape(-1)), out, 3, in1=H.crop(sk, 2, 3), slope=0.3)])
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+BWD_CASES = [(8, 8, 3, 1, 12), (8, 16, 3, 1, 10), (16, 32, 3, 1, 8), (32, 32, 3, 1, 8), (16, 1, 3, 1, 12),
+             (1, 8, 3, 1, 12), (32, 32, 1, 1, 5)]
+
+
+@pytest.mark.parametrize("CI,CO,k,s,n", BWD_CASES)
+def test_conv_input_gradient_stride1(H, oracle_lib, CI, CO, k, s, n):
+    rng = np.random.default_rng(CI + CO)
+    x_shape = (2, n, n, n, CI)
+    w = rnd(rng, k, k, k, CI, CO) * 0.2
+    o = n - k + 1
+    g = rnd(rng, 2, o, o, o, CO)
+    saved = rnd(rng, *x_shape)
+    ref = oracle_lib.leaky_relu_grad_from_out(oracle_lib.conv_bwd_data(g, w, x_shape), saved)
+    out = torch.empty(x_shape, dtype=torch.float32, device="cuda")
+    H.run([H.conv_launch("t", dev(g), dev(w.reshape(-1)), out, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI,
+                         gate=dev(saved))])
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("C,n", [(8, 14), (16, 13), (32, 10)])
+def test_conv_input_gradient_stride2(H, oracle_lib, C, n):
+    """Conv3DBackpropInput of the k4 s2 VALID layers, incl. the untouched last voxel when n is odd."""
+    rng = np.random.default_rng(C)
+    x_shape = (1, n, n, n, C)
+    w = rnd(rng, 4, 4, 4, C, C) * 0.1
+    o = n // 2 - 1
+    g = rnd(rng, 1, o, o, o, C)
+    saved = rnd(rng, *x_shape)
+    skipg = rnd(rng, 1, n - 4, n - 4, n - 4, C)
+    full = oracle_lib.conv_bwd_data(g, w, x_shape, 2, 0)
+    full[:, 2:n - 2, 2:n - 2, 2:n - 2, :] += skipg
+    ref = oracle_lib.leaky_relu_grad_from_out(full, saved)
+    out = torch.empty(x_shape, dtype=torch.float32, device="cuda")
+    H.run([H.conv_launch("t", dev(g), dev(w.reshape(-1)), out, 4, 2, 0, transposed=True, gate=dev(saved),
+                         add=dev(skipg), add_off=2)])
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("CI,CO,n", [(32, 16, 7), (16, 8, 9)])
+def test_conv_transpose_forward_dropout(H, oracle_lib, CI, CO, n):
+    """Conv3DTranspose(k4,s2,'same') -> Dropout(0.5) -> LeakyReLU (models/utils.py:129-135)."""
+    rng = np.random.default_rng(CI)
+    x = rnd(rng, 2, n, n, n, CI)
+    w = rnd(rng, 4, 4, 4, CO, CI) * 0.1
+    c = oracle_lib.convT_fwd(x, w, 2, 1)
+    keep = oracle_lib.dropout_mask(c.shape, 42, 5, 3).astype(np.float32) * 2
+    ref = oracle_lib.leaky_relu(c * keep)
+    out = torch.empty(c.shape, dtype=torch.float32, device="cuda")
+    step = torch.tensor([3], dtype=torch.int32, device="cuda")
+    H.run([H.conv_launch("t", dev(x), dev(w.reshape(-1)), out, 4, 2, 1, transposed=True, slope=0.3,
+                         dropout=(42, 5, step))])
+    got = out.cpu().numpy()
+    assert rel_err(got, ref) < TOL
+    assert 0.45 < (got == 0).mean() < 0.55
+
+
+@pytest.mark.parametrize("CI,CO,n", [(32, 16, 6), (16, 8, 7)])
+def test_conv_transpose_input_gradient(H, oracle_lib, CI, CO, n):
+    rng = np.random.default_rng(CO)
+    w = rnd(rng, 4, 4, 4, CO, CI) * 0.1
+    g = rnd(rng, 1, 2 * n, 2 * n, 2 * n, CO)
+    saved = rnd(rng, 1, n, n, n, CI)
+    ref = oracle_lib.leaky_relu_grad_from_out(oracle_lib.convT_bwd_data(g, w, saved.shape, 2, 1), saved)
+    out = torch.empty(saved.shape, dtype=torch.float32, device="cuda")
+    H.run([H.conv_launch("t", dev(g), dev(w.reshape(-1)), out, 4, 2, 1, gate=dev(saved))])
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+def test_input_gradient_split_through_concat(H, oracle_lib):
+    """d(cat) -> [d(up) gated by LeakyReLU'+Dropout | raw d(skip)] in one launch."""
+    rng = np.random.default_rng(3)
+    w = rnd(rng, 3, 3, 3, 16, 16) * 0.1
+    g = rnd(rng, 1, 8, 8, 8, 16)
+    up = rnd(rng, 1, 10, 10, 10, 8)
+    full = oracle_lib.conv_bwd_data(g, w, (1, 10, 10, 10, 16))
+    keep = oracle_lib.dropout_mask(up.shape, 9, 1, 0).astype(np.float32) * 2
+    ref0 = oracle_lib.leaky_relu_grad_from_out(full[..., :8], up) * keep
+    ref1 = full[..., 8:]
+    o0 = torch.empty(up.shape, dtype=torch.float32, device="cuda")
+    o1 = torch.empty(up.shape, dtype=torch.float32, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    H.run([H.conv_launch("t", dev(g), dev(w.reshape(-1)), o0, 3, 1, 2, layout=H.TEM_W_FLIP_CO_CI, out1=o1,
+                         gate=dev(up), dropout=(9, 1, step))])
+    assert rel_err(o0.cpu().numpy(), ref0) < TOL
+    assert rel_err(o1.cpu().numpy(), ref1) < TOL
+
+
+BWW_CASES = [(1, 8, 3, 1, 0, 14), (8, 8, 3, 1, 0, 12), (8, 8, 4, 2, 0, 14), (8, 16, 3, 1, 0, 10), (16, 16, 4, 2, 0, 11),
+             (16, 32, 3, 1, 0, 8), (32, 32, 3, 1, 0, 8), (32, 16, 3, 1, 0, 8), (16, 1, 3, 1, 0, 10), (32, 32, 4, 2, 0, 10),
+             (32, 32, 1, 1, 0, 6), (32, 1, 1, 1, 0, 6), (1, 8, 3, 1, 4, 8)]
+
+
+@pytest.mark.parametrize("CI,CO,k,s,pad,n", BWW_CASES)
+def test_kernel_gradient(H, oracle_lib, CI, CO, k, s, pad, n):
+    rng = np.random.default_rng(CI * 7 + CO)
+    x = rnd(rng, 2, n, n, n + 1, CI)
+    o = [(d + 2 * pad - k) // s + 1 for d in (n, n, n + 1)]
+    g = rnd(rng, 2, o[0], o[1], o[2], CO)
+    ref = oracle_lib.conv_bwd_weight(x, g, (k, k, k), s, pad)
+    nslab, P = 5, ref.size + 3
+    slabs = torch.full((nslab, P), 7.0, dtype=torch.float32, device="cuda")
+    out = torch.empty(ref.size, dtype=torch.float32, device="cuda")
+    H.run([H.bww_launch("t", dev(x), dev(g), slabs.view(-1)[2:], P, nslab, k, s, pad),
+           H.reduce_slabs_launch("r", slabs.view(-1)[2:], nslab, ref.size, P, out)])
+    assert rel_err(out.cpu().numpy().reshape(ref.shape), ref) < TOL
+    assert float(slabs[:, :2].min()) == 7.0 and float(slabs[:, -1].min()) == 7.0     # nothing written outside
+
+
+def test_kernel_gradient_concat_and_transpose_layout(H, oracle_lib):
+    rng = np.random.default_rng(11)
+    up, skip = rnd(rng, 1, 9, 9, 9, 8), rnd(rng, 1, 12, 12, 12, 8)
+    g = rnd(rng, 1, 7, 7, 7, 16)
+    ref = oracle_lib.conv_bwd_weight(np.concatenate([up, skip[:, 1:10, 1:10, 1:10]], -1), g, (3, 3, 3))
+    slabs = torch.zeros((4, ref.size), dtype=torch.float32, device="cuda")
+    out = torch.empty(ref.size, dtype=torch.float32, device="cuda")
+    sk = dev(skip)
+    H.run([H.bww_launch("t", dev(up), dev(g), slabs.view(-1), ref.size, 4, 3, in1=H.crop(sk, 1, 2)),
+           H.reduce_slabs_launch("r", slabs.view(-1), 4, ref.size, ref.size, out)])
+    assert rel_err(out.cpu().numpy().reshape(ref.shape), ref) < TOL
+    # Conv3DTranspose kernel gradient in Keras layout (tap, CO, CI): roles of input / gradient swap
+    x = rnd(rng, 1, 6, 6, 6, 16)
+    gy = rnd(rng, 1, 12, 12, 12, 8)
+    refT = oracle_lib.convT_bwd_weight(x, gy, (4, 4, 4), 2, 1)
+    slabs = torch.zeros((3, refT.size), dtype=torch.float32, device="cuda")
+    out = torch.empty(refT.size, dtype=torch.float32, device="cuda")
+    H.run([H.bww_launch("t", dev(gy), dev(x), slabs.view(-1), refT.size, 3, 4, 2, 1),
+           H.reduce_slabs_launch("r", slabs.view(-1), 3, refT.size, refT.size, out)])
+    assert rel_err(out.cpu().numpy().reshape(refT.shape), refT) < TOL
+
+
+def test_losses_and_adam(H, oracle_lib):
+    rng = np.random.default_rng(5)
+    z = rnd(rng, 2, 4, 4, 4, 1) * 3
+    losses = torch.zeros(8, dtype=torch.float64, device="cuda")
+    for target in (0, 1):
+        for gamma in (2.0, 1.5):
+            l_ref, g_ref = oracle_lib.focal_logits(z, target, gamma)
+            dz = torch.empty(z.shape, dtype=torch.float32, device="cuda")
+            losses.zero_()
+            H.run([H.focal_logits_launch("t", dev(z), target, gamma, losses, 0b101, 2.0, dz, 3.0)])
+            got = losses.cpu().numpy()
+            assert abs(got[0] - 2 * l_ref) < 1e-6 * abs(2 * l_ref) and got[0] == got[2] and got[1] == 0
+            assert rel_err(dz.cpu().numpy(), 3 * g_ref) < 1e-5
+    a = rnd(rng, 1, 9, 9, 9, 1)
+    b = a + rnd(rng, 1, 9, 9, 9, 1) * 1.5
+    b[0, 0, 0, :3, 0] = a[0, 0, 0, :3, 0]                       # exact matches: t == 1 (clipped branch)
+    b[0, 1, 1, 1, 0] = a[0, 1, 1, 1, 0] + 5.0                   # |a-b| > 2: t < 0 (clipped low)
+    for gamma in (2.0, 3.0):
+        l_ref, g_ref = oracle_lib.focal_prob_match(a, b, gamma)
+        db = torch.empty(a.shape, dtype=torch.float32, device="cuda")
+        losses.zero_()
+        H.run([H.focal_match_launch("t", dev(a), dev(b), gamma, losses, 0b10, 4.0, db, 4.0)])
+        assert abs(losses.cpu().numpy()[1] - 4 * l_ref) < 2e-6 * abs(4 * l_ref)
+        assert rel_err(db.cpu().numpy(), 4 * g_ref) < 1e-5
+    th, g = rnd(rng, 1000), rnd(rng, 1000)
+    m, v = np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+    dth, dm, dv, dg = dev(th), dev(m), dev(v), dev(g)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for t in range(1, 4):
+        th, m, v = oracle_lib.adam_keras(th, g, m, v, t)
+        H.run([H.adam_launch("adam", dth, dg, dm, dv, step), H.step_tick_launch(step)])
+    assert rel_err(dth.cpu().numpy(), th) < 1e-6 and rel_err(dv.cpu().numpy(), v) < 1e-6
+    assert int(step.item()) == 3
+
+
+def test_uint8_boundaries(H, oracle_lib):
+    rng = np.random.default_rng(1)
+    u = rng.integers(0, 256, (5, 6, 7), dtype=np.uint8)
+    ref = oracle_lib.standardize(oracle_lib.scale_u8(u)[..., 0], (0.1, 0.7))
+    out = torch.empty(u.shape, dtype=torch.float32, device="cuda")
+    H.u8_to_f32_std(torch.from_numpy(u).cuda(), out, 0.1, 0.7)
+    assert np.array_equal(out.cpu().numpy(), ref)               # op-by-op fp32: bit-exact
+    y = (rng.standard_normal((1, 5, 6, 7, 1)) * 2).astype(np.float32)     # includes wrap-around values
+    refu = oracle_lib.to_u8(y, (0.05, 0.6))[0, ..., 0]
+    outu = torch.zeros((5, 6, 7), dtype=torch.uint8, device="cuda")
+    H.f32_unstd_to_u8(dev(y), outu, 0.05, 0.6)
+    assert np.array_equal(outu.cpu().numpy(), refu)             # byte output: bit-exact

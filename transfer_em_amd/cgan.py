@@ -1,0 +1,324 @@
+"""Cycle GAN network (mirror of reference transfer_em/cgan.py) on hand-written HIP kernels.
+
+`EM2EM` keeps the reference's constructor, `train`, `train_step`, `predict`,
+`make_checkpoint` and attributes (`generator_g/f`, `discriminator_x/y`, `buffer`,
+`outdimsize`, `is3d`).  The train step is compiled once per batch shape into a static list
+of kernel launches (see models/generator.py, models/discriminator.py):
+
+  * the reference's four tape.gradient sweeps (cgan.py:207-215) are executed as the exact
+    two-sweep equivalent: generators see S = gen_g + gen_f + total_cycle + id_x + id_y,
+    discriminators their own loss;
+  * all four Keras-Adam updates use gradients of the same pre-update forward
+    (cgan.py:218-228: simultaneous update);
+  * data parallelism (the MirroredStrategy the reference lists as TODO, cgan.py:8-11): one
+    process per GPU, local-batch-mean losses, ONE all-reduce of the flat gradient vector of
+    all four networks, identical Adam update on every rank.
+"""
+import glob
+import os
+import re
+import time
+
+import numpy as np
+import torch
+
+from . import hip_ops as H
+from .debug import accuracy, generate_images
+from .models.discriminator import *   # noqa: F401,F403  (reference does the same star imports)
+from .models.generator import *       # noqa: F401,F403
+from .models.discriminator import DiscBackward, DiscForward, discriminator
+from .models.generator import GenBackward, GenForward, unet_generator
+
+# generator call sites of one train step, in the reference's order (cgan.py:152-181)
+CALL_G_FAKE_Y, CALL_F_CYC_X, CALL_F_FAKE_X, CALL_G_CYC_Y, CALL_F_SAME_X, CALL_G_SAME_Y = range(6)
+# slots of the returned loss tuple (cgan.py:230)
+L_TOTAL_G, L_TOTAL_F, L_DISC_Y, L_DISC_X, L_GEN_G, L_GEN_F, L_CYCLE = range(7)
+
+
+def _bits(*slots):
+    m = 0
+    for s in slots:
+        m |= 1 << s
+    return m
+
+
+class _CompiledStep:
+    """Static launch plan of one EM2EM.train_step for a fixed (batch, dimsize)."""
+
+    def __init__(self, model, batch, direct=False):
+        m, is3d, dev = model, model.is3d, model.device
+        n, b, gamma = m.dimsize, m.buffer, float(m.focal_gamma)
+        shp = (batch, n if is3d else 1, n, n, 1)
+        self.real_x = torch.zeros(shp, dtype=torch.float32, device=dev)
+        self.real_y = torch.zeros(shp, dtype=torch.float32, device=dev)
+        self.losses = torch.zeros(8, dtype=torch.float64, device=dev)
+        G, F, DX, DY = m.generator_g, m.generator_f, m.discriminator_x, m.discriminator_y
+        drop = lambda call: (m.seed, call, m.step_dev)
+        cr = lambda t, c: H.crop(t, c, c, is3d)
+        kw = dict(direct=direct)
+
+        # ---- forward (cgan.py:152-189)
+        f_g1 = GenForward(G, self.real_x, training=True, drop=drop(CALL_G_FAKE_Y), **kw)
+        f_f2 = GenForward(F, f_g1.y, in_pad=b, training=True, drop=drop(CALL_F_CYC_X), **kw)
+        f_f1 = GenForward(F, self.real_y, training=True, drop=drop(CALL_F_FAKE_X), **kw)
+        f_g2 = GenForward(G, f_f1.y, in_pad=b, training=True, drop=drop(CALL_G_CYC_Y), **kw)
+        f_f3 = GenForward(F, self.real_x, training=True, drop=drop(CALL_F_SAME_X), **kw)
+        f_g3 = GenForward(G, self.real_y, training=True, drop=drop(CALL_G_SAME_Y), **kw)
+        x_c, y_c = cr(self.real_x, b), cr(self.real_y, b)
+        d_xr = DiscForward(DX, x_c, **kw)
+        d_yr = DiscForward(DY, y_c, **kw)
+        d_xf = DiscForward(DX, f_f1.y, **kw)
+        d_yf = DiscForward(DY, f_g1.y, **kw)
+        self.fwd = dict(g1=f_g1, f2=f_f2, f1=f_f1, g2=f_g2, f3=f_f3, g3=f_g3, dxr=d_xr, dyr=d_yr, dxf=d_xf, dyf=d_yf)
+        forward = []
+        for p in (f_g1, f_f2, f_f1, f_g2, f_f3, f_g3, d_xr, d_yr, d_xf, d_yf):
+            forward += p.launches
+
+        # ---- losses and their gradients (cgan.py:110-142,192-203)
+        z = lambda t: torch.zeros_like(t)
+        dz_gen_g, dz_gen_f = z(d_yf.z), z(d_xf.z)
+        dz_rx, dz_fx, dz_ry, dz_fy = z(d_xr.z), z(d_xf.z), z(d_yr.z), z(d_yf.z)
+        dcyc_x, dcyc_y = z(f_f2.y), z(f_g2.y)          # zero outside the cropped window, forever
+        dsame_x, dsame_y = z(f_f3.y), z(f_g3.y)
+        Ls = self.losses
+        loss = [
+            H.focal_logits_launch("loss.gen_g", d_yf.z, 1, gamma, Ls, _bits(L_TOTAL_G, L_GEN_G), 2.0, dz_gen_g, 2.0),
+            H.focal_logits_launch("loss.gen_f", d_xf.z, 1, gamma, Ls, _bits(L_TOTAL_F, L_GEN_F), 2.0, dz_gen_f, 2.0),
+            H.focal_match_launch("loss.cyc_x", cr(self.real_x, 2 * b), cr(f_f2.y, b), gamma, Ls,
+                                 _bits(L_TOTAL_G, L_TOTAL_F, L_CYCLE), 4.0, cr(dcyc_x, b), 4.0),
+            H.focal_match_launch("loss.cyc_y", cr(self.real_y, 2 * b), cr(f_g2.y, b), gamma, Ls,
+                                 _bits(L_TOTAL_G, L_TOTAL_F, L_CYCLE), 4.0, cr(dcyc_y, b), 4.0),
+            H.focal_match_launch("loss.id_y", y_c, f_g3.y, gamma, Ls, _bits(L_TOTAL_G), 2.0, dsame_y, 2.0),
+            H.focal_match_launch("loss.id_x", x_c, f_f3.y, gamma, Ls, _bits(L_TOTAL_F), 2.0, dsame_x, 2.0),
+            H.focal_logits_launch("loss.dx_real", d_xr.z, 1, gamma, Ls, _bits(L_DISC_X), 1.0, dz_rx, 1.0),
+            H.focal_logits_launch("loss.dx_fake", d_xf.z, 0, gamma, Ls, _bits(L_DISC_X), 1.0, dz_fx, 1.0),
+            H.focal_logits_launch("loss.dy_real", d_yr.z, 1, gamma, Ls, _bits(L_DISC_Y), 1.0, dz_ry, 1.0),
+            H.focal_logits_launch("loss.dy_fake", d_yf.z, 0, gamma, Ls, _bits(L_DISC_Y), 1.0, dz_fy, 1.0),
+        ]
+
+        # ---- backward.  Kernel-gradient slabs: one [nslab, P] set per weight-gradient pass.
+        ns = m.nslab
+        sg = torch.zeros((3 * ns, G.params.count), dtype=torch.float32, device=dev)
+        sf = torch.zeros((3 * ns, F.params.count), dtype=torch.float32, device=dev)
+        sdx = torch.zeros((2 * ns, DX.params.count), dtype=torch.float32, device=dev)
+        sdy = torch.zeros((2 * ns, DY.params.count), dtype=torch.float32, device=dev)
+        b_g3 = GenBackward(f_g3, dsame_y, sg[0:ns], **kw)
+        b_f3 = GenBackward(f_f3, dsame_x, sf[0:ns], **kw)
+        b_f2 = GenBackward(f_f2, dcyc_x, sf[ns:2 * ns], need_dx=True, **kw)      # dx = d S / d fake_y (cycle part)
+        b_g2 = GenBackward(f_g2, dcyc_y, sg[ns:2 * ns], need_dx=True, **kw)
+        # adversarial part through the discriminators (input gradient only), summed onto the cycle part
+        a_dy = DiscBackward(d_yf, dz_gen_g, need_dx=True, need_dw=False, **kw)
+        a_dx = DiscBackward(d_xf, dz_gen_f, need_dx=True, need_dw=False, **kw)
+        add_y = H.copy_view_launch("dfake_y+=adv", a_dy.dx, b_f2.dx, add=True)
+        add_x = H.copy_view_launch("dfake_x+=adv", a_dx.dx, b_g2.dx, add=True)
+        b_g1 = GenBackward(f_g1, b_f2.dx, sg[2 * ns:3 * ns], **kw)
+        b_f1 = GenBackward(f_f1, b_g2.dx, sf[2 * ns:3 * ns], **kw)
+        w_dxr = DiscBackward(d_xr, dz_rx, sdx[0:ns], **kw)
+        w_dxf = DiscBackward(d_xf, dz_fx, sdx[ns:2 * ns], **kw)
+        w_dyr = DiscBackward(d_yr, dz_ry, sdy[0:ns], **kw)
+        w_dyf = DiscBackward(d_yf, dz_fy, sdy[ns:2 * ns], **kw)
+        self.bwd = dict(g3=b_g3, f3=b_f3, f2=b_f2, g2=b_g2, ady=a_dy, adx=a_dx, g1=b_g1, f1=b_f1,
+                        dxr=w_dxr, dxf=w_dxf, dyr=w_dyr, dyf=w_dyf)
+        backward = []
+        for p in (b_g3, b_f3, b_f2, b_g2, a_dy, a_dx):
+            backward += p.launches
+        backward += [add_y, add_x]
+        for p in (b_g1, b_f1, w_dxr, w_dxf, w_dyr, w_dyf):
+            backward += p.launches
+        reduce_ = [
+            H.reduce_slabs_launch("grad.g", sg, 3 * ns, G.params.count, G.params.count, G.params.grad),
+            H.reduce_slabs_launch("grad.f", sf, 3 * ns, F.params.count, F.params.count, F.params.grad),
+            H.reduce_slabs_launch("grad.dx", sdx, 2 * ns, DX.params.count, DX.params.count, DX.params.grad),
+            H.reduce_slabs_launch("grad.dy", sdy, 2 * ns, DY.params.count, DY.params.count, DY.params.grad),
+        ]
+        self.compute = forward + loss + backward + reduce_
+        self._keep = (sg, sf, sdx, sdy, dz_gen_g, dz_gen_f, dz_rx, dz_fx, dz_ry, dz_fy, dcyc_x, dcyc_y, dsame_x, dsame_y)
+
+        # ---- optimizer (cgan.py:218-228); gradients are averaged over ranks by grad_scale
+        ws = m.world_size
+        P = lambda net: net.params
+        self.update = [H.adam_launch("adam." + nm, P(net).theta, P(net).grad, P(net).m, P(net).v, m.step_dev,
+                                     grad_scale=1.0 / ws)
+                       for nm, net in (("g", G), ("f", F), ("dx", DX), ("dy", DY))]
+        self.update.append(H.step_tick_launch(m.step_dev))
+
+
+class EM2EM(object):
+    """Creates CGAN model for 1-channel 2d or 3d data and provides functions to train and predict.
+
+    Compatible tensor dimension sizes: 74 (the only entry of the mounted reference's VALID_DIMS),
+    132 (every reference notebook / utils.save_model default) and 260.
+    """
+
+    def __init__(self, dimsize, exp_name, is3d=True, norm_type="instancenorm", ckpt_restore=None, wf=8,
+                 focal_gamma=2, disc_prior=None, device=None, seed=42, weight_seeds=(0, 1, 2, 3), nslab=32,
+                 process_group=None, checkpoint_root="./checkpoints"):
+        if dimsize < 74:
+            raise RuntimeError("minimum dimension allowed is 74")            # cgan.py:52-53
+        H.require_gpu()
+        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.dimsize, self.exp_name, self.is3d = dimsize, exp_name, is3d
+        self.focal_gamma, self.nslab = focal_gamma, nslab
+        self.pg = process_group
+        self.world_size = torch.distributed.get_world_size(process_group) if self._dist() else 1
+        self.rank = torch.distributed.get_rank(process_group) if self._dist() else 0
+        self.seed = int(seed) + self.rank            # independent dropout stream per replica
+
+        sd = weight_seeds
+        self.discriminator_x = discriminator(is3d, norm_type=norm_type, wf=wf, device=self.device, seed=sd[2])
+        self.discriminator_y = discriminator(is3d, norm_type=norm_type, wf=wf, disc_prior=disc_prior,
+                                             device=self.device, seed=sd[3])
+        self.generator_g, dimsize2 = unet_generator(dimsize, is3d, norm_type=norm_type, wf=wf, device=self.device,
+                                                    seed=sd[0])
+        self.generator_f, _ = unet_generator(dimsize, is3d, norm_type=norm_type, wf=wf, device=self.device, seed=sd[1])
+        assert (dimsize2 % 2) == 0                   # dimsize2 should always be even (cgan.py:63-64)
+        self.buffer = (dimsize - dimsize2) // 2
+        self.outdimsize = dimsize2
+
+        # one flat gradient vector for all four networks -> one all-reduce per step
+        self._nets = (self.generator_g, self.generator_f, self.discriminator_x, self.discriminator_y)
+        total = sum(n.params.count for n in self._nets)
+        self.grad_all = torch.zeros(total, dtype=torch.float32, device=self.device)
+        o = 0
+        for n in self._nets:
+            n.params.grad = self.grad_all[o:o + n.params.count]
+            o += n.params.count
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # Adam t-1 / dropout step
+        self._steps = {}
+
+        # checkpoints (cgan.py:84-103): ./checkpoints/train_{exp_name}/ckpt-N, max_to_keep=50
+        self.checkpoint_path = os.path.join(checkpoint_root, f"train_{exp_name}")
+        self.max_to_keep = 50
+        if ckpt_restore is not None:
+            self._restore(ckpt_restore)
+            print(f"checkpoint {ckpt_restore} restored")
+        else:
+            latest = self.latest_checkpoint()
+            if latest:
+                self._restore(latest)
+                print('Latest checkpoint restored!!')
+        if self._dist():
+            self._broadcast_parameters()
+
+    # ------------------------------------------------------------------ distributed helpers
+    def _dist(self):
+        return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    def _broadcast_parameters(self):
+        for n in self._nets:
+            for t in n.params.state().values():
+                torch.distributed.broadcast(t, src=0, group=self.pg)
+        torch.distributed.broadcast(self.step_dev, src=0, group=self.pg)
+
+    # ------------------------------------------------------------------ checkpointing
+    def _ckpt_files(self):
+        files = glob.glob(os.path.join(self.checkpoint_path, "ckpt-*.pt"))
+        return sorted(files, key=lambda f: int(re.search(r"ckpt-(\d+)\.pt$", f).group(1)))
+
+    def latest_checkpoint(self):
+        f = self._ckpt_files()
+        return f[-1] if f else None
+
+    def make_checkpoint(self, epoch_num):
+        if self.rank != 0:
+            return None
+        os.makedirs(self.checkpoint_path, exist_ok=True)
+        files = self._ckpt_files()
+        idx = int(re.search(r"ckpt-(\d+)\.pt$", files[-1]).group(1)) + 1 if files else 1
+        path = os.path.join(self.checkpoint_path, f"ckpt-{idx}.pt")
+        state = {"step": int(self.step_dev.item()), "dimsize": self.dimsize, "is3d": self.is3d}
+        for nm, n in zip(("generator_g", "generator_f", "discriminator_x", "discriminator_y"), self._nets):
+            state[nm] = {k: v.detach().cpu() for k, v in n.params.state().items()}
+        torch.save(state, path)
+        for old in self._ckpt_files()[:-self.max_to_keep]:
+            os.remove(old)
+        print(f"Saving checkpoint for epoch {epoch_num} at {path}")
+        return path
+
+    def _restore(self, path):
+        state = torch.load(path, map_location="cpu", weights_only=True)
+        for nm, n in zip(("generator_g", "generator_f", "discriminator_x", "discriminator_y"), self._nets):
+            for k, t in n.params.state().items():
+                src = state[nm][k]
+                assert src.shape == t.shape, f"checkpoint {path}: {nm}.{k} has shape {tuple(src.shape)}"
+                t.copy_(src)
+        self.step_dev.fill_(int(state["step"]))
+
+    # ------------------------------------------------------------------ training
+    def _compiled(self, batch):
+        st = self._steps.get(batch)
+        if st is None:
+            st = self._steps[batch] = _CompiledStep(self, batch)
+        return st
+
+    def train_step(self, real_x, real_y):
+        """One CycleGAN step (cgan.py:144-230).  real_x/real_y: (B, [D,] H, W, 1) float32.
+        Returns the 7 losses (total_gen_g, total_gen_f, disc_y, disc_x, gen_g, gen_f,
+        total_cycle) as a device tensor -- no host synchronisation."""
+        real_x = self._as_input(real_x)
+        real_y = self._as_input(real_y)
+        st = self._compiled(real_x.shape[0])
+        st.real_x.copy_(real_x, non_blocking=True)
+        st.real_y.copy_(real_y, non_blocking=True)
+        return self._run_step(st)
+
+    def _run_step(self, st):
+        s = H.current_stream()
+        st.losses.zero_()
+        H.run(st.compute, s)
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.grad_all, group=self.pg)       # RCCL over xGMI (sum; Adam scales)
+        H.run(st.update, s)
+        return st.losses[:7].to(torch.float32)
+
+    def _as_input(self, t, check_size=True):
+        t = torch.as_tensor(np.asarray(t) if not torch.is_tensor(t) else t)
+        t = t.to(self.device, torch.float32, non_blocking=True)
+        if not self.is3d and t.dim() == 4:
+            t = t.unsqueeze(1)                       # (B,H,W,1) -> (B,1,H,W,1)
+        assert t.dim() == 5 and t.shape[-1] == 1, tuple(t.shape)
+        assert not check_size or t.shape[3] == self.dimsize, tuple(t.shape)
+        return t
+
+    def train(self, train_input, train_target, epochs=3000, start=0, debug=False, sample=None, sample_gt=None,
+              enable_eager=False, num_samples=4096, check_freq=1):
+        """Main function for training model (cgan.py:242-287).  train_input / train_target are
+        re-iterable batch sources (transfer_em_amd.datasets or any iterable of arrays)."""
+        for epoch in range(start, start + epochs):
+            t0 = time.time()
+            loss = torch.zeros(7, dtype=torch.float32, device=self.device)
+            count = 0
+            for data_f, data_g in zip(train_input, train_target):
+                loss += self.train_step(data_f, data_g)      # accumulated on device; one sync per epoch
+                count += 1
+            loss = (loss / max(count, 1)).cpu().numpy()
+            if self.world_size > 1:
+                lt = torch.from_numpy(loss).to(self.device)
+                torch.distributed.all_reduce(lt, group=self.pg)
+                loss = (lt / self.world_size).cpu().numpy()
+            if self.rank == 0:
+                print(f"Epoch {epoch+1} loss [g_gen_total, f_gen_total, disc_y, disc_x, g_gen_only, f_gen_only, "
+                      f"cycle]: {loss}")
+            if (epoch + 1) % check_freq == 0:
+                self.make_checkpoint(epoch + 1)
+                if debug and sample is not None:
+                    sample_pred = self.predict(sample)
+                    if sample_gt is not None:
+                        gt = H.crop(self._as_input(sample_gt), self.buffer, is3d=self.is3d)
+                        print(f"Accuracy on sample: {accuracy(gt[0], sample_pred[0])}")
+                    generate_images(sample, sample_pred)
+            if self.rank == 0:
+                print(f"Time taken for epoch {epoch+1} is {time.time()-t0}")
+
+    def predict(self, data):
+        """Generate prediction from trained generator (cgan.py:289-293; inference mode: dropout off)."""
+        t = self._as_input(data, check_size=False)
+        return self.generator_g(t)
+
+    def plot_discriminator(self, location):
+        raise NotImplementedError("plot_model needs Keras graphs (cgan.py:232-240); not part of the HIP path")
+
+    plot_generator = plot_discriminator
+
+
+CycleGan = EM2EM   # BASELINE.json north_star alias

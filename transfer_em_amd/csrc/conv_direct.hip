@@ -1,0 +1,256 @@
+// conv_direct.hip -- shape-generic direct convolution kernels (VALU, one output voxel per
+// lane, weights through the scalar path).  They cover every (C_in, C_out, k, stride, pad)
+// the hot path uses and are the fallback for geometries the LDS/MFMA-tiled kernels in
+// conv_mfma.hip do not take.  NDHWC float32; see include/tem_hip.h for the contract.
+//
+// Data movement: lane i of a wave owns output voxel x0+i, so the C_in floats a tap needs
+// are contiguous per lane and the wave reads one contiguous stride-C_in span of the input
+// row (coalesced dwordx4 loads, re-used through L1/L2 by the k^3 taps); the kernel taps are
+// wave-uniform and come through s_load.  Bounds (padding / crop) are handled by predicated
+// loads, never by divergent control flow.
+#include "tem_common.h"
+
+namespace {
+
+struct ConvDev {
+  const float *in0, *in1;
+  int64_t i0N, i0D, i0H, i0W, i1N, i1D, i1H, i1W;
+  int32_t N, D, H, W;              // input extents
+  const float *w;
+  int32_t kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  float *out0, *out1;
+  int64_t o0N, o0D, o0H, o0W, o1N, o1D, o1H, o1W;
+  int32_t OD, OH, OW;
+  int64_t total;                   // N*OD*OH*OW (conv) or per-class count (convT)
+  EpilogueDev ep;
+};
+
+template <int C>
+__device__ __forceinline__ void load_vec(float (&v)[C], const float *p, bool ok) {
+  if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < C; i += 4) {
+      float4 t = ok ? *reinterpret_cast<const float4 *>(p + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i) v[i] = ok ? p[i] : 0.f;
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void store_vec(float *p, const float (&v)[C]) {
+  if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < C; i += 4) *reinterpret_cast<float4 *>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; ++i) p[i] = v[i];
+  }
+}
+
+// acc[co] += sum_ci xv[ci] * W(ci, co); wt points at the tap's C_in x C_out block.
+// FLIP: block is stored [co][ci] (TEM_W_FLIP_CO_CI / transposed-conv layout), else [ci][co].
+template <int CIP, int CI, int CO, bool COCI>
+__device__ __forceinline__ void fma_block(float (&acc)[CO], const float (&xv)[CIP], const float *wt, int ci_base) {
+#pragma unroll
+  for (int ci = 0; ci < CIP; ++ci) {
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      float wv = COCI ? wt[co * CI + ci_base + ci] : wt[(ci_base + ci) * CO + co];
+      acc[co] = fmaf(xv[ci], wv, acc[co]);
+    }
+  }
+}
+
+template <int CO0, int CO1>
+__device__ __forceinline__ void finish(const ConvDev &p, float (&acc)[CO0 + CO1], int n, int z, int y, int x) {
+  float v0[CO0];
+#pragma unroll
+  for (int i = 0; i < CO0; ++i) v0[i] = acc[i];
+  apply_epilogue<CO0>(p.ep, v0, n, z, y, x, 0, p.OD, p.OH, p.OW, CO0);
+  store_vec<CO0>(p.out0 + n * p.o0N + z * p.o0D + y * p.o0H + x * p.o0W, v0);
+  if constexpr (CO1 > 0) {
+    float v1[CO1];
+#pragma unroll
+    for (int i = 0; i < CO1; ++i) v1[i] = acc[CO0 + i];
+    store_vec<CO1>(p.out1 + n * p.o1N + z * p.o1D + y * p.o1H + x * p.o1W, v1);
+  }
+}
+
+// ------------------------------------------------------------------ conv (gather form)
+template <int CI0, int CI1, int CO0, int CO1, bool FLIP>
+__global__ __launch_bounds__(256) void conv_direct_k(ConvDev p) {
+  constexpr int CI = CI0 + CI1, CO = CO0 + CO1;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  int x = (int)(idx % p.OW); int64_t r = idx / p.OW;
+  int y = (int)(r % p.OH); r /= p.OH;
+  int z = (int)(r % p.OD); int n = (int)(r / p.OD);
+
+  float acc[CO];
+#pragma unroll
+  for (int i = 0; i < CO; ++i) acc[i] = 0.f;
+
+  const int ntap = p.kd * p.kh * p.kw;
+  int tap = 0;
+  for (int dz = 0; dz < p.kd; ++dz) {
+    int iz = z * p.sd + dz - p.pd;
+    bool okz = iz >= 0 && iz < p.D;
+    for (int dy = 0; dy < p.kh; ++dy) {
+      int iy = y * p.sh + dy - p.ph;
+      bool oky = okz && iy >= 0 && iy < p.H;
+      for (int dx = 0; dx < p.kw; ++dx, ++tap) {
+        int ix = x * p.sw + dx - p.pw;
+        bool ok = oky && ix >= 0 && ix < p.W;
+        const float *wt = p.w + (int64_t)(FLIP ? ntap - 1 - tap : tap) * (CI * CO);
+        float xv[CI0];
+        load_vec<CI0>(xv, p.in0 + n * p.i0N + iz * p.i0D + iy * p.i0H + ix * p.i0W, ok);
+        fma_block<CI0, CI, CO, FLIP>(acc, xv, wt, 0);
+        if constexpr (CI1 > 0) {
+          float xw[CI1];
+          load_vec<CI1>(xw, p.in1 + n * p.i1N + iz * p.i1D + iy * p.i1H + ix * p.i1W, ok);
+          fma_block<CI1, CI, CO, FLIP>(acc, xw, wt, CI0);
+        }
+      }
+    }
+  }
+  finish<CO0, CO1>(p, acc, n, z, y, x);
+}
+
+// ------------------------------------------------------------------ transposed conv
+// One launch covers all output residue classes (blockIdx.y); inside a class every lane uses
+// the same taps, so the weights stay wave-uniform.  out[o] = sum_{j,t: o = j*s + t - p}.
+template <int CI0, int CO0, int CO1>
+__global__ __launch_bounds__(256) void convT_direct_k(ConvDev p) {
+  constexpr int CI = CI0, CO = CO0 + CO1;
+  int cls = blockIdx.y;
+  int rx = cls % p.sw, ry = (cls / p.sw) % p.sh, rz = cls / (p.sw * p.sh);
+  int QW = (p.OW - rx + p.sw - 1) / p.sw, QH = (p.OH - ry + p.sh - 1) / p.sh, QD = (p.OD - rz + p.sd - 1) / p.sd;
+  int64_t cnt = (int64_t)p.N * QD * QH * QW;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= cnt) return;
+  int qx = (int)(idx % QW); int64_t r = idx / QW;
+  int qy = (int)(r % QH); r /= QH;
+  int qz = (int)(r % QD); int n = (int)(r / QD);
+  int x = qx * p.sw + rx, y = qy * p.sh + ry, z = qz * p.sd + rz;
+
+  float acc[CO];
+#pragma unroll
+  for (int i = 0; i < CO; ++i) acc[i] = 0.f;
+
+  // taps with t == (o + p) mod s; j = (o + p - t) / s
+  int tz0 = (rz + p.pd) % p.sd, ty0 = (ry + p.ph) % p.sh, tx0 = (rx + p.pw) % p.sw;
+  for (int dz = tz0; dz < p.kd; dz += p.sd) {
+    int jz = (z + p.pd - dz) / p.sd;
+    bool okz = (z + p.pd - dz) >= 0 && jz < p.D;
+    for (int dy = ty0; dy < p.kh; dy += p.sh) {
+      int jy = (y + p.ph - dy) / p.sh;
+      bool oky = okz && (y + p.ph - dy) >= 0 && jy < p.H;
+      for (int dx = tx0; dx < p.kw; dx += p.sw) {
+        int jx = (x + p.pw - dx) / p.sw;
+        bool ok = oky && (x + p.pw - dx) >= 0 && jx < p.W;
+        int tap = (dz * p.kh + dy) * p.kw + dx;
+        const float *wt = p.w + (int64_t)tap * (CI * CO);
+        float xv[CI0];
+        load_vec<CI0>(xv, p.in0 + n * p.i0N + jz * p.i0D + jy * p.i0H + jx * p.i0W, ok);
+        fma_block<CI0, CI, CO, true>(acc, xv, wt, 0);
+      }
+    }
+  }
+  finish<CO0, CO1>(p, acc, n, z, y, x);
+}
+
+int fill_dev(const tem_conv_args *a, ConvDev &p, bool transposed) {
+  if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->out0) || !a->w) return TEM_EINVAL;
+  if (a->kd < 1 || a->kh < 1 || a->kw < 1 || a->sd < 1 || a->sh < 1 || a->sw < 1) return TEM_EINVAL;
+  const tem_view &i0 = a->in0, &o0 = a->out0;
+  p.in0 = i0.ptr; p.i0N = i0.sN; p.i0D = i0.sD; p.i0H = i0.sH; p.i0W = i0.sW;
+  p.N = i0.N; p.D = i0.D; p.H = i0.H; p.W = i0.W;
+  p.in1 = nullptr;
+  if (a->in1.ptr) {
+    const tem_view &i1 = a->in1;
+    if (i1.N != i0.N || i1.D != i0.D || i1.H != i0.H || i1.W != i0.W) return TEM_ESHAPE;
+    p.in1 = i1.ptr; p.i1N = i1.sN; p.i1D = i1.sD; p.i1H = i1.sH; p.i1W = i1.sW;
+  }
+  p.w = a->w;
+  p.kd = a->kd; p.kh = a->kh; p.kw = a->kw; p.sd = a->sd; p.sh = a->sh; p.sw = a->sw;
+  p.pd = a->pd; p.ph = a->ph; p.pw = a->pw;
+  p.out0 = o0.ptr; p.o0N = o0.sN; p.o0D = o0.sD; p.o0H = o0.sH; p.o0W = o0.sW;
+  p.OD = o0.D; p.OH = o0.H; p.OW = o0.W;
+  p.out1 = nullptr;
+  if (a->out1.ptr) {
+    const tem_view &o1 = a->out1;
+    if (o1.N != o0.N || o1.D != o0.D || o1.H != o0.H || o1.W != o0.W) return TEM_ESHAPE;
+    p.out1 = o1.ptr; p.o1N = o1.sN; p.o1D = o1.sD; p.o1H = o1.sH; p.o1W = o1.sW;
+  }
+  if (o0.N != i0.N) return TEM_ESHAPE;
+  if (!transposed) {
+    // every output voxel must be defined by the geometry: o*s - p + (k-1) may exceed the
+    // input only through zero padding, which predicated loads provide -- no constraint.
+  }
+  p.total = (int64_t)o0.N * o0.D * o0.H * o0.W;
+  p.ep = make_epilogue(a->ep);
+  if (a->ep.gate.ptr) {
+    const tem_view &g = a->ep.gate;
+    if (g.N != o0.N || g.D != o0.D || g.H != o0.H || g.W != o0.W || g.C < o0.C) return TEM_ESHAPE;
+  }
+  if (a->ep.add.ptr && (a->ep.add.C < o0.C || a->ep.add.N != o0.N)) return TEM_ESHAPE;
+  return TEM_OK;
+}
+
+}  // namespace
+
+#define CONV_CASE(ci0, ci1, co0, co1)                                                         \
+  if (CI0 == ci0 && CI1 == ci1 && CO0 == co0 && CO1 == co1) {                                 \
+    if (flip)                                                                                 \
+      hipLaunchKernelGGL((conv_direct_k<ci0, ci1, co0, co1, true>), grid, dim3(256), 0, st, p); \
+    else                                                                                      \
+      hipLaunchKernelGGL((conv_direct_k<ci0, ci1, co0, co1, false>), grid, dim3(256), 0, st, p); \
+    TEM_CHECK_LAUNCH();                                                                       \
+    return TEM_OK;                                                                            \
+  }
+
+extern "C" int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream) {
+  ConvDev p{};
+  int rc = fill_dev(a, p, false);
+  if (rc) return rc;
+  const int CI0 = a->in0.C, CI1 = a->in1.ptr ? a->in1.C : 0;
+  const int CO0 = a->out0.C, CO1 = a->out1.ptr ? a->out1.C : 0;
+  const bool flip = a->w_layout == TEM_W_FLIP_CO_CI;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((p.total + 255) / 256));
+  // forward shapes
+  CONV_CASE(1, 0, 8, 0) CONV_CASE(1, 0, 16, 0) CONV_CASE(1, 0, 32, 0)
+  CONV_CASE(8, 0, 8, 0) CONV_CASE(8, 0, 16, 0) CONV_CASE(8, 0, 1, 0)
+  CONV_CASE(16, 0, 16, 0) CONV_CASE(16, 0, 32, 0) CONV_CASE(16, 0, 8, 0) CONV_CASE(16, 0, 1, 0)
+  CONV_CASE(32, 0, 32, 0) CONV_CASE(32, 0, 16, 0) CONV_CASE(32, 0, 1, 0)
+  CONV_CASE(8, 8, 16, 0) CONV_CASE(16, 16, 32, 0)
+  // split outputs (input-gradient through a concat)
+  CONV_CASE(16, 0, 8, 8) CONV_CASE(32, 0, 16, 16)
+  return TEM_EUNSUPPORTED;
+}
+
+#define CONVT_CASE(ci0, co0, co1)                                                       \
+  if (CI0 == ci0 && CO0 == co0 && CO1 == co1) {                                         \
+    hipLaunchKernelGGL((convT_direct_k<ci0, co0, co1>), grid, dim3(256), 0, st, p);     \
+    TEM_CHECK_LAUNCH();                                                                 \
+    return TEM_OK;                                                                      \
+  }
+
+extern "C" int tem_conv_transpose_direct(const tem_conv_args *a, tem_stream_t stream) {
+  ConvDev p{};
+  int rc = fill_dev(a, p, true);
+  if (rc) return rc;
+  if (a->in1.ptr) return TEM_EUNSUPPORTED;
+  const int CI0 = a->in0.C;
+  const int CO0 = a->out0.C, CO1 = a->out1.ptr ? a->out1.C : 0;
+  hipStream_t st = (hipStream_t)stream;
+  int ncls = a->sd * a->sh * a->sw;
+  int64_t qmax = (int64_t)p.N * ((p.OD + a->sd - 1) / a->sd) * ((p.OH + a->sh - 1) / a->sh) * ((p.OW + a->sw - 1) / a->sw);
+  dim3 grid((unsigned)((qmax + 255) / 256), (unsigned)ncls);
+  CONVT_CASE(32, 16, 0) CONVT_CASE(16, 8, 0)                       // Conv3DTranspose forward
+  CONVT_CASE(8, 8, 0) CONVT_CASE(16, 16, 0) CONVT_CASE(32, 32, 0)  // input-grad of the k4 s2 convs
+  return TEM_EUNSUPPORTED;
+}

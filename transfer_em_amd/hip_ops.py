@@ -1,0 +1,230 @@
+"""Prepared launches of the libtem_hip.so kernels on torch-owned device memory.
+
+PyTorch is used here for device memory and streams only: every arithmetic operation is a
+hand-written HIP kernel reached through the C ABI in include/tem_hip.h.  A `Launch` binds
+one entry point to a fully populated argument struct once (static shapes), so a train step
+is a flat list of `lib.fn(byref(args), stream)` calls -- cheap on the host and capturable
+into a hipGraph because no argument changes between steps (per-step scalars live in device
+memory).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import tem_view, tem_conv_args, tem_bww_args, TEM_W_TAP_CI_CO, TEM_W_FLIP_CO_CI  # noqa: F401
+
+LEAKY = 0.3            # tf.keras.layers.LeakyReLU() default alpha (reference models/utils.py:77)
+NULL_VIEW = tem_view()
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.TemError("transfer_em_amd needs an AMD GPU (no CPU fallback); torch.cuda.is_available() is False")
+    return _lib.load()
+
+
+def view(t):
+    """tem_view of a float32 NDHWC torch tensor (any strides with unit channel stride)."""
+    assert t.dtype == torch.float32 and t.dim() == 5, (t.dtype, t.shape)
+    assert t.shape[4] == 1 or t.stride(4) == 1, "channel stride must be 1"
+    v = tem_view()
+    v.ptr = t.data_ptr()
+    v.N, v.D, v.H, v.W, v.C = t.shape
+    v.sN, v.sD, v.sH, v.sW = t.stride()[:4]
+    return v
+
+
+def crop(t, lo, hi=None, is3d=True):
+    """Cropping3D / Cropping2D as a strided view (reference cgan.py:163-183, generator.py:80-84)."""
+    hi = lo if hi is None else hi
+    D, H, W = t.shape[1:4]
+    if is3d:
+        return t[:, lo:D - hi, lo:H - hi, lo:W - hi, :]
+    return t[:, :, lo:H - hi, lo:W - hi, :]
+
+
+def current_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Launch:
+    """One kernel launch with frozen arguments.  `keep` pins the tensors the struct points to."""
+    __slots__ = ("fn", "args", "name", "keep", "meta")
+
+    def __init__(self, fn, args, name, keep=(), meta=None):
+        self.fn, self.args, self.name, self.keep = fn, args, name, keep
+        # meta: kernel symbol (as rocprofv3 prints it), algorithmic flops and bytes of this launch
+        # (bytes = 4*(C_in*in_vox + C_out*out_vox + ntap*C_in*C_out), flops = 2*ntap*C_in*C_out*vox)
+        self.meta = meta or {}
+
+    def __call__(self, stream):
+        rc = self.fn(*self.args, stream)
+        if rc:
+            _lib.check(rc, self.name)
+
+
+def run(launches, stream=None):
+    s = current_stream() if stream is None else stream
+    for l in launches:
+        l(s)
+
+
+def _k3(k, is3d):
+    return (k, k, k) if is3d else (1, k, k)
+
+
+def _s3(s, is3d):
+    return (s, s, s) if is3d else (1, s, s)
+
+
+def _p3(p, is3d):
+    return (p, p, p) if is3d else (0, p, p)
+
+
+def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=None, layout=TEM_W_TAP_CI_CO,
+                transposed=False, slope=1.0, bias=None, gate=None, gate_slope=LEAKY, add=None, add_off=0,
+                dropout=None, direct=False):
+    """Build a tem_conv / tem_conv_transpose launch.  `w` and `bias` are 1-D float32 tensors
+    (slices of a network's flat parameter vector); dropout = (seed, site, step_dev_tensor)."""
+    lib = _lib.load()
+    a = tem_conv_args()
+    keep = [in0, w, out0]
+    a.in0 = view(in0)
+    if in1 is not None:
+        a.in1 = view(in1); keep.append(in1)
+    a.w = w.data_ptr()
+    a.w_layout = layout
+    a.kd, a.kh, a.kw = _k3(k, is3d)
+    a.sd, a.sh, a.sw = _s3(s, is3d)
+    a.pd, a.ph, a.pw = _p3(p, is3d)
+    a.out0 = view(out0)
+    if out1 is not None:
+        a.out1 = view(out1); keep.append(out1)
+    ep = a.ep
+    ep.slope = slope
+    if bias is not None:
+        ep.bias = bias.data_ptr(); keep.append(bias)
+    if gate is not None:
+        ep.gate = view(gate); ep.gate_slope = gate_slope; keep.append(gate)
+    if add is not None:
+        ep.add = view(add); keep.append(add)
+        off = _p3(add_off, is3d)
+        ep.add_off[0], ep.add_off[1], ep.add_off[2] = off
+    if dropout is not None:
+        seed, site, step_dev = dropout
+        ep.dropout = 1
+        ep.seed, ep.site = seed, site
+        ep.step_dev = step_dev.data_ptr(); keep.append(step_dev)
+    if transposed:
+        fn = lib.tem_conv_transpose_direct if direct else lib.tem_conv_transpose
+    else:
+        fn = lib.tem_conv_direct if direct else lib.tem_conv
+    ci0, ci1 = in0.shape[4], (in1.shape[4] if in1 is not None else 0)
+    co0, co1 = out0.shape[4], (out1.shape[4] if out1 is not None else 0)
+    ntap = a.kd * a.kh * a.kw
+    vin, vout = in0.numel() // ci0, out0.numel() // co0
+    ci, co = ci0 + ci1, co0 + co1
+    meta = dict(flops=2.0 * ntap * ci * co * (vin if transposed else vout),
+                bytes=4.0 * (ci * vin + co * vout + ntap * ci * co),
+                kernel=(f"convT_direct_k<{ci0}, {co0}, {co1}>" if transposed else
+                        f"conv_direct_k<{ci0}, {ci1}, {co0}, {co1}, {'true' if layout == TEM_W_FLIP_CO_CI else 'false'}>"))
+    return Launch(fn, (C.byref(a),), name, keep + [a], meta)
+
+
+def bww_launch(name, in0, dout, slabs, slab_stride, nslab, k, s=1, p=0, *, is3d=True, in1=None, accumulate=False):
+    """Kernel-gradient launch; `slabs` is the 1-D float32 tensor slice where slab 0 starts."""
+    lib = _lib.load()
+    a = tem_bww_args()
+    keep = [in0, dout, slabs]
+    a.in0 = view(in0)
+    if in1 is not None:
+        a.in1 = view(in1); keep.append(in1)
+    a.dout = view(dout)
+    a.kd, a.kh, a.kw = _k3(k, is3d)
+    a.sd, a.sh, a.sw = _s3(s, is3d)
+    a.pd, a.ph, a.pw = _p3(p, is3d)
+    a.slabs = slabs.data_ptr()
+    a.slab_stride = slab_stride
+    a.nslab = nslab
+    a.accumulate = int(accumulate)
+    ci = in0.shape[4] + (in1.shape[4] if in1 is not None else 0)
+    co = dout.shape[4]
+    ntap = a.kd * a.kh * a.kw
+    vin, vout = in0.numel() // in0.shape[4], dout.numel() // co
+    mt = 6 if ci >= 32 else (3 if ci >= 16 else 2)
+    meta = dict(flops=2.0 * ntap * ci * co * vout, bytes=4.0 * (ci * vin + co * vout + ntap * ci * co),
+                kernel=f"bww_mfma_k<{mt}, {2 if co > 16 else 1}>")
+    return Launch(lib.tem_conv_bwd_weight, (C.byref(a),), name, keep + [a], meta)
+
+
+def reduce_slabs_launch(name, slabs, nslab, n, slab_stride, out, accumulate=False, scale=1.0):
+    lib = _lib.load()
+    return Launch(lib.tem_reduce_slabs, (slabs.data_ptr(), nslab, n, slab_stride, out.data_ptr(), int(accumulate),
+                                         scale), name, [slabs, out])
+
+
+def channel_sum_launch(name, g, out, accumulate=False):
+    lib = _lib.load()
+    v = view(g)
+    return Launch(lib.tem_channel_sum, (C.byref(v), out.data_ptr(), int(accumulate)), name, [g, out, v])
+
+
+def focal_logits_launch(name, z, target, gamma, losses, slot_mask, loss_scale, dz=None, grad_scale=1.0):
+    lib = _lib.load()
+    vz = view(z)
+    vd = view(dz) if dz is not None else tem_view()
+    return Launch(lib.tem_focal_logits, (C.byref(vz), target, gamma, losses.data_ptr(), slot_mask, loss_scale,
+                                         C.byref(vd), grad_scale), name, [z, dz, losses, vz, vd])
+
+
+def focal_match_launch(name, a, b, gamma, losses, slot_mask, loss_scale, db=None, grad_scale=1.0):
+    lib = _lib.load()
+    va, vb = view(a), view(b)
+    vd = view(db) if db is not None else tem_view()
+    return Launch(lib.tem_focal_match, (C.byref(va), C.byref(vb), gamma, losses.data_ptr(), slot_mask, loss_scale,
+                                        C.byref(vd), grad_scale), name, [a, b, db, losses, va, vb, vd])
+
+
+def adam_launch(name, theta, grad, m, v, step_dev, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    """tf.keras.optimizers.Adam(2e-4, beta_1=0.5) (reference cgan.py:69-73)."""
+    lib = _lib.load()
+    return Launch(lib.tem_adam_keras, (theta.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), theta.numel(),
+                                       lr, beta1, beta2, eps, grad_scale, step_dev.data_ptr()), name,
+                  [theta, grad, m, v, step_dev])
+
+
+def step_tick_launch(step_dev):
+    lib = _lib.load()
+    return Launch(lib.tem_step_tick, (step_dev.data_ptr(),), "step_tick", [step_dev])
+
+
+def fill_launch(name, t, value=0.0):
+    lib = _lib.load()
+    assert t.is_contiguous()
+    return Launch(lib.tem_fill_f32, (t.data_ptr(), t.numel(), value), name, [t])
+
+
+def copy_view_launch(name, src, dst, add=False):
+    lib = _lib.load()
+    vs, vd = view(src), view(dst)
+    fn = lib.tem_add_view if add else lib.tem_copy_view
+    return Launch(fn, (C.byref(vs), C.byref(vd)), name, [src, dst, vs, vd])
+
+
+def u8_to_f32_std(src_u8, dst_f32, mean, std, stream=None):
+    lib = _lib.load()
+    assert src_u8.dtype == torch.uint8 and src_u8.is_contiguous() and dst_f32.is_contiguous()
+    assert src_u8.numel() == dst_f32.numel()
+    _lib.check(lib.tem_u8_to_f32_std(src_u8.data_ptr(), dst_f32.data_ptr(), src_u8.numel(), float(mean), float(std),
+                                     current_stream() if stream is None else stream), "tem_u8_to_f32_std")
+
+
+def f32_unstd_to_u8(y, out_u8, mean, std, stream=None):
+    """y: (1,D,H,W,1) float32 view; out_u8: (D,H,W) uint8 view (any strides)."""
+    lib = _lib.load()
+    vy = view(y)
+    assert out_u8.dtype == torch.uint8 and tuple(out_u8.shape) == tuple(y.shape[1:4])
+    oD, oH, oW = out_u8.stride()
+    _lib.check(lib.tem_f32_unstd_to_u8(C.byref(vy), out_u8.data_ptr(), oD, oH, oW, float(mean), float(std),
+                                       current_stream() if stream is None else stream), "tem_f32_unstd_to_u8")

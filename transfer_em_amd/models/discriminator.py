@@ -1,0 +1,168 @@
+"""PatchGAN-style discriminator (mirror of reference transfer_em/models/discriminator.py).
+
+`discriminator(is3d, norm_type, wf, disc_prior)` keeps the reference signature.  Quirks of
+the reference graph that are observable and therefore kept: the hard-coded 16-filter "HACK"
+conv makes the graph consistent only for wf == 8 (discriminator.py:45-57,60,72); in 2-D the
+HACK conv is fed the raw input so Downsample_1 is dead (discriminator.py:49-51); Downsample_3's
+LeakyReLU is followed by a second one (models/utils.py:83 + discriminator.py:74), i.e. slope 0.09.
+"""
+from collections import OrderedDict
+
+import torch
+
+from .. import hip_ops as H
+from .params import ParamSet
+
+DOUBLE_LEAKY = float(torch.tensor(0.3, dtype=torch.float32) * torch.tensor(0.3, dtype=torch.float32))
+
+
+def discriminator_param_shapes(is3d=True, wf=8):
+    if wf != 8:
+        raise RuntimeError("the reference discriminator graph is only shape-consistent for wf == 8")
+    k3 = (3, 3, 3) if is3d else (1, 3, 3)
+    k4 = (4, 4, 4) if is3d else (1, 4, 4)
+    k1 = (1, 1, 1)
+    s = OrderedDict()
+    if is3d:
+        s["d1a"] = k3 + (1, 64 // wf)                 # Downsample_1 (discriminator.py:39-40)
+        s["d1b"] = k4 + (64 // wf, 64 // wf)
+        s["hack"] = k3 + (64 // wf, 16)               # discriminator.py:45-47
+    else:
+        s["hack"] = k3 + (1, 16)                      # discriminator.py:49-51 (raw input)
+    s["d2a"] = k3 + (128 // wf, 256 // wf)            # Downsample_2
+    s["d2b"] = k4 + (256 // wf, 256 // wf)
+    s["d3a"] = k3 + (32, 32)                          # Downsample_3 (dims=32 hard-coded, :60,72)
+    s["d3b"] = k4 + (32, 32)
+    s["p1"] = k1 + (32, 256 // wf)                    # discriminator.py:78-80
+    s["p2"] = k1 + (256 // wf, 1)                     # discriminator.py:97-99 (with bias)
+    s["p2_bias"] = (1,)
+    return s
+
+
+def discriminator_edges(n, is3d=True):
+    e = OrderedDict()
+    e["in"] = n
+    if is3d:
+        e["d1a"] = n - 2
+        e["d1b"] = e["d1a"] // 2 - 1
+        e["hack"] = e["d1b"] - 2
+    else:
+        e["hack"] = n - 2
+    e["d2a"] = e["hack"] - 2
+    e["d2b"] = e["d2a"] // 2 - 1
+    e["d3a"] = e["d2b"] - 2
+    e["d3b"] = e["d3a"] // 2 - 1
+    e["p1"] = e["d3b"]
+    e["p2"] = e["d3b"]
+    return e
+
+
+_ORDER3 = ("d1a", "d1b", "hack", "d2a", "d2b", "d3a", "d3b", "p1", "p2")
+_ORDER2 = ("hack", "d2a", "d2b", "d3a", "d3b", "p1", "p2")
+_GEOM = {"d1a": (3, 1), "d1b": (4, 2), "hack": (3, 1), "d2a": (3, 1), "d2b": (4, 2), "d3a": (3, 1), "d3b": (4, 2),
+         "p1": (1, 1), "p2": (1, 1)}
+_SLOPE = {"d3b": DOUBLE_LEAKY, "p2": 1.0}
+
+
+class DiscForward:
+    def __init__(self, net, x, direct=False):
+        P, is3d = net.params, net.is3d
+        self.net, self.x = net, x
+        N = x.shape[0]
+        e = self.edges = discriminator_edges(x.shape[3], is3d)
+        self.order = _ORDER3 if is3d else _ORDER2
+        A = self.act = {}
+        L = self.launches = []
+        prev = x
+        for name in self.order:
+            n = e[name]
+            if n < 1:
+                raise RuntimeError(f"input edge {x.shape[3]} is too small for the discriminator")
+            A[name] = torch.empty((N, n if is3d else 1, n, n, P.shapes[name][-1]), dtype=torch.float32,
+                                  device=x.device)
+            k, s = _GEOM[name]
+            L.append(H.conv_launch("d." + name, prev, P.w(name), A[name], k, s, 0, is3d=is3d if k > 1 else True,
+                                   slope=_SLOPE.get(name, H.LEAKY), bias=P.w("p2_bias") if name == "p2" else None,
+                                   direct=direct))
+            prev = A[name]
+        self.z = A["p2"]
+
+    def run(self, stream=None):
+        H.run(self.launches, stream)
+        return self.z
+
+
+class DiscBackward:
+    """Adjoint of a DiscForward for one upstream gradient dz.  need_dw=False is the
+    generator's adversarial path (input gradient only, cgan.py:192-193,207-210)."""
+
+    def __init__(self, fwd, dz, slabs=None, need_dx=False, need_dw=True, direct=False):
+        net, A = fwd.net, fwd.act
+        P, is3d = net.params, net.is3d
+        self.fwd, self.dz = fwd, dz
+        order = fwd.order
+        G = self.grads = {k: torch.empty_like(A[k]) for k in order[:-1]}
+        self.dx = torch.empty_like(fwd.x) if need_dx else None
+        if need_dw:
+            nslab, stride = slabs.shape
+            flat = slabs.view(-1)
+        L = self.launches = []
+        g_out = dz
+        for i in range(len(order) - 1, -1, -1):
+            name = order[i]
+            k, s = _GEOM[name]
+            i3 = is3d if k > 1 else True
+            xin = A[order[i - 1]] if i > 0 else fwd.x
+            if need_dw:
+                L.append(H.bww_launch("d.bww." + name, xin, g_out, flat[P.offsets[name]:], stride, nslab, k, s, 0,
+                                      is3d=i3))
+                if name == "p2":
+                    L.append(H.channel_sum_launch("d.bias", g_out, flat[P.offsets["p2_bias"]:]))
+            if i == 0 and not need_dx:
+                break
+            dst = G[order[i - 1]] if i > 0 else self.dx
+            gate = A[order[i - 1]] if i > 0 else None
+            gslope = _SLOPE.get(order[i - 1], H.LEAKY) if i > 0 else 1.0
+            if s == 1:
+                L.append(H.conv_launch("d.bd." + name, g_out, P.w(name), dst, k, 1, k - 1, is3d=i3,
+                                       layout=H.TEM_W_FLIP_CO_CI, gate=gate, gate_slope=gslope, direct=direct))
+            else:
+                L.append(H.conv_launch("d.bd." + name, g_out, P.w(name), dst, k, s, 0, is3d=i3, transposed=True,
+                                       gate=gate, gate_slope=gslope, direct=direct))
+            g_out = dst
+
+    def run(self, stream=None):
+        H.run(self.launches, stream)
+
+
+class Discriminator:
+    def __init__(self, is3d=True, norm_type="instancenorm", wf=8, disc_prior=None, device=None, seed=None):
+        H.require_gpu()
+        if disc_prior is not None:
+            raise NotImplementedError("disc_prior (frozen prior-net features, discriminator.py:62-66) is not "
+                                      "built yet -- SURVEY 8(f) row 4")
+        self.is3d, self.wf, self.norm_type = is3d, wf, norm_type
+        self.device = torch.device(device or "cuda")
+        self.params = ParamSet(discriminator_param_shapes(is3d, wf), self.device, seed)
+        self._plans = {}
+
+    @property
+    def trainable_variables(self):
+        return [self.params.theta]
+
+    def __call__(self, x, training=False):
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
+        key = tuple(x.shape)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = DiscForward(self, torch.empty_like(x))
+        plan.x.copy_(x)
+        return plan.run().clone()
+
+
+def discriminator(is3d=True, norm_type='instancenorm', wf=8, disc_prior=None, device=None, seed=None):
+    """PatchGan discriminator model (reference discriminator.py:14-105)."""
+    return Discriminator(is3d, norm_type, wf, disc_prior, device, seed)
+
+
+create_discriminator = discriminator   # BASELINE.json north_star alias

@@ -1,0 +1,233 @@
+"""U-Net generator of the CycleGAN (mirror of reference transfer_em/models/generator.py).
+
+`unet_generator(dimsize, is3d, norm_type, wf)` keeps the reference signature and returns
+`(model, out_dim)` (generator.py:22,117).  The model is a static launch plan over hand-written
+HIP kernels: forward = 12 fused conv(+LeakyReLU/Dropout) launches with the skip crops and
+concats folded into the consumer's loads; backward = input-gradient launches with the
+LeakyReLU/Dropout gradients and the skip-gradient merge fused into their epilogues, plus one
+matrix-core kernel-gradient launch per layer.
+"""
+from collections import OrderedDict
+
+import torch
+
+from .. import hip_ops as H
+from .params import ParamSet
+
+# technically invalid sizes will still work but off-by-one problems could arise (generator.py:17-20).
+# The mounted reference lists only 74; 132 is what every notebook, utils.save_model and
+# BASELINE.json use, 260 is the large-tile inference size.
+VALID_DIMS = [74, 132, 260]
+VALID_OUT = [40, 96, 224]
+
+
+def generator_edges(n):
+    """Spatial edge after each layer (generator.py:48-115 comments: 74,72,70,34,32,15,26,24,44,40)."""
+    e = OrderedDict()
+    e["in"] = n
+    e["c0"] = n - 2
+    e["d1a"] = e["c0"] - 2
+    e["d1b"] = e["d1a"] // 2 - 1
+    e["d2a"] = e["d1b"] - 2
+    e["d2b"] = e["d2a"] // 2 - 1
+    e["u2a"] = e["d2b"] - 2
+    e["u2b"] = e["u2a"] * 2
+    e["mid"] = e["u2b"] - 2
+    e["u1a"] = e["mid"] - 2
+    e["u1b"] = e["u1a"] * 2
+    e["f1"] = e["u1b"] - 2
+    e["f2"] = e["f1"] - 2
+    return e
+
+
+def generator_out(n):
+    return generator_edges(n)["f2"]
+
+
+def skip_crop(dim_dn, dim_up):
+    """(low, high) crop of the skip tensor; the high side takes the odd voxel (generator.py:74-78)."""
+    c1 = (dim_dn - dim_up) // 2
+    return c1, c1 + ((dim_dn - dim_up) % 2)
+
+
+def generator_param_shapes(is3d=True, wf=8):
+    c1, c2, cm, cf = 64 // wf, 128 // wf, 256 // wf, 128 // wf
+    k3 = (3, 3, 3) if is3d else (1, 3, 3)
+    k4 = (4, 4, 4) if is3d else (1, 4, 4)
+    return OrderedDict([
+        ("c0", k3 + (1, c1)),                                        # generator.py:53-56
+        ("d1a", k3 + (c1, c1)), ("d1b", k4 + (c1, c1)),              # Downsample_1
+        ("d2a", k3 + (c1, c2)), ("d2b", k4 + (c2, c2)),              # Downsample_2
+        ("u2a", k3 + (c2, 2 * c2)), ("u2b", k4 + (c2, 2 * c2)),      # Upsample_2 (transposed: ..., CO, CI)
+        ("mid", k3 + (2 * c2, cm)),                                  # generator.py:95-98
+        ("u1a", k3 + (cm, 2 * c1)), ("u1b", k4 + (c1, 2 * c1)),      # Upsample_1
+        ("f1", k3 + (2 * c1, cf)), ("f2", k3 + (cf, 1)),             # generator.py:107-114
+    ])
+
+
+def dropout_site(call_id, block):
+    """Philox stream id of one Dropout layer instance: block 0 = Upsample_2, 1 = Upsample_1."""
+    return call_id * 4 + block
+
+
+class GenForward:
+    """Activations + launches of one generator call site (static shapes)."""
+
+    def __init__(self, net, x, in_pad=0, training=False, drop=None, direct=False):
+        P, is3d = net.params, net.is3d
+        self.net, self.x, self.in_pad, self.training, self.drop = net, x, in_pad, training, drop
+        N = x.shape[0]
+        e = generator_edges(x.shape[3] + 2 * in_pad)
+        self.edges = e
+        ch = {k: s[-1] for k, s in P.shapes.items()}
+        ch["u2b"], ch["u1b"] = P.shapes["u2b"][3], P.shapes["u1b"][3]
+
+        def alloc(layer):
+            n = e[layer]
+            return torch.empty((N, n if is3d else 1, n, n, ch[layer]), dtype=torch.float32, device=x.device)
+
+        A = self.act = {k: alloc(k) for k in ("c0", "d1a", "d1b", "d2a", "d2b", "u2a", "u2b", "mid", "u1a", "u1b",
+                                              "f1", "f2")}
+        self.lo1, hi1 = skip_crop(e["d2a"], e["u2b"])
+        self.lo0, hi0 = skip_crop(e["d1a"], e["u1b"])
+        self.skip1 = H.crop(A["d2a"], self.lo1, hi1, is3d)
+        self.skip0 = H.crop(A["d1a"], self.lo0, hi0, is3d)
+        dr = (lambda blk: (drop[0], dropout_site(drop[1], blk), drop[2])) if (training and drop) else (lambda blk: None)
+        kw = dict(is3d=is3d, direct=direct)
+        L = self.launches = []
+        cv = H.conv_launch
+        L.append(cv("g.c0", x, P.w("c0"), A["c0"], 3, 1, in_pad, slope=H.LEAKY, **kw))
+        L.append(cv("g.d1a", A["c0"], P.w("d1a"), A["d1a"], 3, slope=H.LEAKY, **kw))
+        L.append(cv("g.d1b", A["d1a"], P.w("d1b"), A["d1b"], 4, 2, slope=H.LEAKY, **kw))
+        L.append(cv("g.d2a", A["d1b"], P.w("d2a"), A["d2a"], 3, slope=H.LEAKY, **kw))
+        L.append(cv("g.d2b", A["d2a"], P.w("d2b"), A["d2b"], 4, 2, slope=H.LEAKY, **kw))
+        L.append(cv("g.u2a", A["d2b"], P.w("u2a"), A["u2a"], 3, slope=H.LEAKY, **kw))
+        L.append(cv("g.u2b", A["u2a"], P.w("u2b"), A["u2b"], 4, 2, 1, transposed=True, slope=H.LEAKY,
+                    dropout=dr(0), **kw))
+        L.append(cv("g.mid", A["u2b"], P.w("mid"), A["mid"], 3, in1=self.skip1, slope=H.LEAKY, **kw))
+        L.append(cv("g.u1a", A["mid"], P.w("u1a"), A["u1a"], 3, slope=H.LEAKY, **kw))
+        L.append(cv("g.u1b", A["u1a"], P.w("u1b"), A["u1b"], 4, 2, 1, transposed=True, slope=H.LEAKY,
+                    dropout=dr(1), **kw))
+        L.append(cv("g.f1", A["u1b"], P.w("f1"), A["f1"], 3, in1=self.skip0, slope=H.LEAKY, **kw))
+        L.append(cv("g.f2", A["f1"], P.w("f2"), A["f2"], 3, slope=1.0, **kw))
+        self.y = A["f2"]
+
+    def run(self, stream=None):
+        H.run(self.launches, stream)
+        return self.y
+
+
+class GenBackward:
+    """Adjoint of one GenForward: fills this call's kernel-gradient slabs and, if asked, dx."""
+
+    def __init__(self, fwd, dy, slabs, need_dx=False, direct=False):
+        net, A, e = fwd.net, fwd.act, fwd.edges
+        P, is3d = net.params, net.is3d
+        N, dev = fwd.x.shape[0], fwd.x.device
+        self.fwd, self.dy, self.slabs = fwd, dy, slabs
+        nslab, stride = slabs.shape[0], slabs.shape[1]
+        flat = slabs.view(-1)
+        ch = {k: s[-1] for k, s in P.shapes.items()}
+        ch["u2b"], ch["u1b"] = P.shapes["u2b"][3], P.shapes["u1b"][3]
+
+        def alloc(layer, c=None):
+            n = e[layer]
+            return torch.empty((N, n if is3d else 1, n, n, ch[layer] if c is None else c), dtype=torch.float32,
+                               device=dev)
+
+        G = self.grads = {k: alloc(k) for k in ("c0", "d1a", "d1b", "d2a", "d2b", "u2a", "u2b", "mid", "u1a", "u1b",
+                                                "f1")}
+        t_skip0 = alloc("u1b", ch["d1a"])          # raw gradient reaching the cropped skip0
+        t_skip1 = alloc("u2b", ch["d2a"])
+        self.dx = torch.empty_like(fwd.x) if need_dx else None
+        dr = (lambda blk: (fwd.drop[0], dropout_site(fwd.drop[1], blk), fwd.drop[2])) \
+            if (fwd.training and fwd.drop) else (lambda blk: None)
+        kw = dict(is3d=is3d, direct=direct)
+        FL, AS = H.TEM_W_FLIP_CO_CI, H.TEM_W_TAP_CI_CO
+        cv = H.conv_launch
+
+        def bww(name, in0, dout, k, s=1, p=0, in1=None):
+            return H.bww_launch("g.bww." + name, in0, dout, flat[P.offsets[name]:], stride, nslab, k, s, p, is3d=is3d,
+                                in1=in1)
+
+        L = self.launches = []
+        L.append(bww("f2", A["f1"], dy, 3))
+        L.append(cv("g.bd.f2", dy, P.w("f2"), G["f1"], 3, 1, 2, layout=FL, gate=A["f1"], **kw))
+        L.append(bww("f1", A["u1b"], G["f1"], 3, in1=fwd.skip0))
+        L.append(cv("g.bd.f1", G["f1"], P.w("f1"), G["u1b"], 3, 1, 2, layout=FL, out1=t_skip0, gate=A["u1b"],
+                    dropout=dr(1), **kw))
+        L.append(bww("u1b", G["u1b"], A["u1a"], 4, 2, 1))
+        L.append(cv("g.bd.u1b", G["u1b"], P.w("u1b"), G["u1a"], 4, 2, 1, layout=AS, gate=A["u1a"], **kw))
+        L.append(bww("u1a", A["mid"], G["u1a"], 3))
+        L.append(cv("g.bd.u1a", G["u1a"], P.w("u1a"), G["mid"], 3, 1, 2, layout=FL, gate=A["mid"], **kw))
+        L.append(bww("mid", A["u2b"], G["mid"], 3, in1=fwd.skip1))
+        L.append(cv("g.bd.mid", G["mid"], P.w("mid"), G["u2b"], 3, 1, 2, layout=FL, out1=t_skip1, gate=A["u2b"],
+                    dropout=dr(0), **kw))
+        L.append(bww("u2b", G["u2b"], A["u2a"], 4, 2, 1))
+        L.append(cv("g.bd.u2b", G["u2b"], P.w("u2b"), G["u2a"], 4, 2, 1, layout=AS, gate=A["u2a"], **kw))
+        L.append(bww("u2a", A["d2b"], G["u2a"], 3))
+        L.append(cv("g.bd.u2a", G["u2a"], P.w("u2a"), G["d2b"], 3, 1, 2, layout=FL, gate=A["d2b"], **kw))
+        L.append(bww("d2b", A["d2a"], G["d2b"], 4, 2))
+        L.append(cv("g.bd.d2b", G["d2b"], P.w("d2b"), G["d2a"], 4, 2, 0, transposed=True, add=t_skip1,
+                    add_off=fwd.lo1, gate=A["d2a"], **kw))
+        L.append(bww("d2a", A["d1b"], G["d2a"], 3))
+        L.append(cv("g.bd.d2a", G["d2a"], P.w("d2a"), G["d1b"], 3, 1, 2, layout=FL, gate=A["d1b"], **kw))
+        L.append(bww("d1b", A["d1a"], G["d1b"], 4, 2))
+        L.append(cv("g.bd.d1b", G["d1b"], P.w("d1b"), G["d1a"], 4, 2, 0, transposed=True, add=t_skip0,
+                    add_off=fwd.lo0, gate=A["d1a"], **kw))
+        L.append(bww("d1a", A["c0"], G["d1a"], 3))
+        L.append(cv("g.bd.d1a", G["d1a"], P.w("d1a"), G["c0"], 3, 1, 2, layout=FL, gate=A["c0"], **kw))
+        L.append(bww("c0", fwd.x, G["c0"], 3, 1, fwd.in_pad))
+        if need_dx:
+            L.append(cv("g.bd.c0", G["c0"], P.w("c0"), self.dx, 3, 1, 2 - fwd.in_pad, layout=FL, **kw))
+        self._keep = (t_skip0, t_skip1)
+
+    def run(self, stream=None):
+        H.run(self.launches, stream)
+
+
+class UNetGenerator:
+    """Callable generator model (the object `unet_generator` returns in place of a tf.keras.Model)."""
+
+    def __init__(self, dimsize, is3d=True, norm_type="instancenorm", wf=8, device=None, seed=None):
+        H.require_gpu()
+        self.dimsize, self.is3d, self.wf = dimsize, is3d, wf
+        self.norm_type = norm_type          # accepted, no effect (reference models/utils.py:75-82 commented out)
+        self.device = torch.device(device or "cuda")
+        self.params = ParamSet(generator_param_shapes(is3d, wf), self.device, seed)
+        self.outdim = generator_out(dimsize)
+        self._plans = {}
+
+    @property
+    def trainable_variables(self):
+        return [self.params.theta]
+
+    def forward_plan(self, x, **kw):
+        return GenForward(self, x, **kw)
+
+    def __call__(self, x, training=False):
+        """Inference forward (Keras __call__ without training=True: dropout off, cgan.py:289-293)."""
+        if training:
+            raise NotImplementedError("training-mode calls go through EM2EM.train_step")
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
+        key = tuple(x.shape)
+        plan = self._plans.get(key)
+        if plan is None:
+            buf = torch.empty_like(x)
+            plan = self._plans[key] = GenForward(self, buf)
+        plan.x.copy_(x)
+        return plan.run().clone()
+
+    predict = __call__
+
+
+def unet_generator(dimsize, is3d=True, norm_type='instancenorm', wf=8, device=None, seed=None):
+    """Modified u-net generator (reference generator.py:22-117).  Returns (model, out_dim)."""
+    # dimsize must be valid at least for the generator (generator.py:35-38)
+    if dimsize not in VALID_DIMS:
+        raise RuntimeError(f"{dimsize} does not allow for valid convolutions")
+    model = UNetGenerator(dimsize, is3d, norm_type, wf, device, seed)
+    return model, model.outdim
+
+
+create_generator = unet_generator      # BASELINE.json north_star alias

@@ -1,0 +1,69 @@
+"""Flat parameter storage shared by the generator and discriminator.
+
+All kernels of one network live in ONE contiguous float32 vector (Keras layouts, creation
+order), with matching flat gradient / Adam-moment vectors: the Adam update and the
+data-parallel all-reduce are then a single launch / a single collective per network.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+class ParamSet:
+    def __init__(self, shapes, device, seed=None):
+        self.shapes = OrderedDict(shapes)
+        self.offsets = OrderedDict()
+        o = 0
+        for k, s in self.shapes.items():
+            self.offsets[k] = o
+            o += int(np.prod(s))
+        self.count = o
+        self.device = torch.device(device)
+        self.theta = torch.zeros(o, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros_like(self.theta)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.initialize(seed)
+
+    def initialize(self, seed=None):
+        """tf.random_normal_initializer(0., 0.02) for kernels, zeros for the bias
+        (reference models/utils.py:58, generator.py:40, discriminator.py:29)."""
+        gen = torch.Generator(device="cpu")
+        if seed is None:
+            gen.seed()
+        else:
+            gen.manual_seed(int(seed))
+        host = torch.zeros(self.count, dtype=torch.float32)
+        for k, s in self.shapes.items():
+            n = int(np.prod(s))
+            if not k.endswith("_bias"):
+                host[self.offsets[k]:self.offsets[k] + n] = torch.randn(n, generator=gen) * 0.02
+        self.theta.copy_(host)
+        self.m.zero_(); self.v.zero_(); self.grad.zero_()
+
+    def w(self, name):
+        """1-D slice of theta holding kernel `name`."""
+        o = self.offsets[name]
+        return self.theta[o:o + int(np.prod(self.shapes[name]))]
+
+    def g(self, name):
+        o = self.offsets[name]
+        return self.grad[o:o + int(np.prod(self.shapes[name]))]
+
+    def load_dict(self, d):
+        """Load kernels from name -> array (Keras layouts)."""
+        host = torch.empty(self.count, dtype=torch.float32)
+        for k, s in self.shapes.items():
+            a = np.asarray(d[k], np.float32)
+            assert tuple(a.shape) == tuple(s), (k, a.shape, s)
+            host[self.offsets[k]:self.offsets[k] + a.size] = torch.from_numpy(a.reshape(-1).copy())
+        self.theta.copy_(host)
+
+    def to_dict(self, which="theta"):
+        host = getattr(self, which).detach().cpu().numpy()
+        return OrderedDict((k, host[self.offsets[k]:self.offsets[k] + int(np.prod(s))].reshape(s).copy())
+                           for k, s in self.shapes.items())
+
+    def state(self):
+        return {"theta": self.theta, "m": self.m, "v": self.v}
