@@ -133,16 +133,19 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle.torch_ref import TimedBaseline
-            cores = os.cpu_count() or 1
+            cores = min(len(os.sched_getaffinity(0)), 16)       # the GPU box grants 16 host cores per GPU
+            TimedBaseline(74, batch=1, is3d=False, threads=cores).step(          # library warm-up, tiny 2-D case
+                torch.zeros(1, 1, 1, 74, 74), torch.zeros(1, 1, 1, 74, 74))
             base = TimedBaseline(n, batch=B, is3d=True, threads=cores)
             cx, cy = rx.cpu().permute(0, 4, 1, 2, 3).contiguous(), ry.cpu().permute(0, 4, 1, 2, 3).contiguous()
-            base.step(cx, cy)                                  # warm-up (oneDNN primitive creation)
             c0 = time.perf_counter()
             base.step(cx, cy)
             cdt = time.perf_counter() - c0
+            print(f"cpu baseline: {cdt:.1f} s/step on {cores} threads", file=sys.stderr, flush=True)
             cpu = dict(value=1.0 / cdt, unit="steps/s", cores=cores, kind="port",
-                       sample=f"1 warm-up + 1 timed train step, 3D {n}^3 batch {B} fp32, oracle/torch_ref.py "
-                              "(PyTorch-CPU/oneDNN restatement of cgan.py:144-230; TF2 itself is not installable here)")
+                       sample=f"1 timed train step (after a 2-D warm-up of the library), 3D {n}^3 batch {B} fp32, "
+                              "oracle/torch_ref.py: PyTorch-CPU/oneDNN restatement of cgan.py:144-230 "
+                              "(TF2 itself is not installable here)")
         steps_per_s = args.steps * world / dt
         out = {
             "metric": "CycleGAN train steps/sec on 132^3 x1 uint8 volumes (per-GPU batch of 1 volume; aggregate over GPUs)",

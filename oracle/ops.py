@@ -236,14 +236,16 @@ def focal_prob_match(a, b, gamma=2.0):
 def adam_keras(theta, g, m, v, t, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-7):
     """tf.keras.optimizers.Adam(2e-4, beta_1=0.5) dense update (cgan.py:69-73,218-228).
 
-    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps)  (eps NOT
-    bias-corrected).  float32 state, float32 arithmetic like ResourceApplyAdam."""
+    Restated from TF's ApplyAdam CPU functor, float32 op for op:
+      alpha = lr*sqrt(1-b2^t)/(1-b1^t);  m += (g-m)*(1-b1);  v += (g*g-v)*(1-b2);
+      theta -= (m*alpha)/(sqrt(v)+eps)        (eps is NOT bias-corrected)."""
     f = np.float32
-    lr_t = f(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+    b1, b2 = f(beta1), f(beta2)
+    alpha = f(lr) * np.sqrt(f(1) - np.power(b2, f(t))) / (f(1) - np.power(b1, f(t)))
     g = np.asarray(g, f)
-    m = (f(beta1) * m + f(1.0 - beta1) * g).astype(f)
-    v = (f(beta2) * v + f(1.0 - beta2) * g * g).astype(f)
-    theta = (theta - lr_t * m / (np.sqrt(v) + f(eps))).astype(f)
+    m = (m + (g - m) * (f(1) - b1)).astype(f)
+    v = (v + (g * g - v) * (f(1) - b2)).astype(f)
+    theta = (theta - (m * f(alpha)) / (np.sqrt(v) + f(eps))).astype(f)
     return theta, m, v
 
 

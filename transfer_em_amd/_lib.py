@@ -6,6 +6,11 @@ the ABI the header declares, importing the kernels raises.
 import ctypes as C
 import os
 
+# PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so).  It has to be in the process BEFORE
+# libtem_hip.so is loaded, so that the library's libamdhip64 dependency resolves to the same runtime
+# that owns torch's device memory and streams (two runtimes in one process => "no device" on launch).
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtem_hip.so")
 

@@ -171,6 +171,7 @@ int launch_bww(const BwwDev &p, hipStream_t st) {
 }  // namespace
 
 extern "C" int tem_conv_bwd_weight(const tem_bww_args *a, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout) || !a->slabs || a->nslab < 1) return TEM_EINVAL;
   BwwDev p{};
   const tem_view &i0 = a->in0, &g = a->dout;
@@ -203,6 +204,7 @@ extern "C" int tem_conv_bwd_weight(const tem_bww_args *a, tem_stream_t stream) {
 
 extern "C" int tem_reduce_slabs(const float *slabs, int32_t nslab, int64_t n, int64_t slab_stride, float *out,
                                 int32_t accumulate, float scale, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!slabs || !out || nslab < 1 || n < 0) return TEM_EINVAL;
   if (n == 0) return TEM_OK;
   hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs,
@@ -212,6 +214,7 @@ extern "C" int tem_reduce_slabs(const float *slabs, int32_t nslab, int64_t n, in
 }
 
 extern "C" int tem_channel_sum(const tem_view *g, float *out, int32_t accumulate, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!g || !tem_view_ok(*g) || !out) return TEM_EINVAL;
   hipLaunchKernelGGL(channel_sum_k, dim3(g->C), dim3(256), 0, (hipStream_t)stream, g->ptr, g->sN, g->sD, g->sH,
                      g->sW, g->N, g->D, g->H, g->W, g->C, out, accumulate);

@@ -213,6 +213,7 @@ int fill_dev(const tem_conv_args *a, ConvDev &p, bool transposed) {
   }
 
 extern "C" int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   ConvDev p{};
   int rc = fill_dev(a, p, false);
   if (rc) return rc;
@@ -240,6 +241,7 @@ extern "C" int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream) {
   }
 
 extern "C" int tem_conv_transpose_direct(const tem_conv_args *a, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   ConvDev p{};
   int rc = fill_dev(a, p, true);
   if (rc) return rc;

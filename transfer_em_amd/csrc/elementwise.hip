@@ -90,15 +90,18 @@ __global__ __launch_bounds__(256) void focal_match_k(V5 a, V5 b, float gamma, do
 __global__ __launch_bounds__(256) void adam_keras_k(float *theta, const float *grad, float *m, float *v, int64_t n,
                                                     float lr, float b1, float b2, float eps, float gscale,
                                                     const uint32_t *step_dev) {
-  // lr_t in double once per thread (cheap next to the streaming update)
-  double t = (double)(*step_dev) + 1.0;
-  float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  // TF's ApplyAdam functor, op for op in float32 (tensorflow/core/kernels/training_ops.cc):
+  //   alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  m += (g - m)*(1 - beta1);
+  //   v += (g*g - v)*(1 - beta2);  var -= (m*alpha) / (sqrt(v) + epsilon)
+  float t = (float)(*step_dev) + 1.f;
+  float alpha = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  float omb1 = 1.f - b1, omb2 = 1.f - b2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float g = gscale * grad[i];
-    float mm = b1 * m[i] + (1.f - b1) * g;
-    float vv = b2 * v[i] + (1.f - b2) * g * g;
+    float mm = m[i] + (g - m[i]) * omb1;
+    float vv = v[i] + (g * g - v[i]) * omb2;
     m[i] = mm; v[i] = vv;
-    theta[i] = theta[i] - lr_t * mm / (sqrtf(vv) + eps);
+    theta[i] = theta[i] - (mm * alpha) / (sqrtf(vv) + eps);
   }
 }
 
@@ -152,6 +155,7 @@ inline bool same_extents(const tem_view &a, const tem_view &b) {
 
 extern "C" int tem_focal_logits(const tem_view *z, int32_t target, float gamma, double *losses, uint32_t slot_mask,
                                 float loss_scale, const tem_view *dz, float grad_scale, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!z || !tem_view_ok(*z) || (target != 0 && target != 1)) return TEM_EINVAL;
   V5 d{};
   if (dz && dz->ptr) { if (!same_extents(*z, *dz)) return TEM_ESHAPE; d = dv(*dz); }
@@ -165,6 +169,7 @@ extern "C" int tem_focal_logits(const tem_view *z, int32_t target, float gamma, 
 
 extern "C" int tem_focal_match(const tem_view *a, const tem_view *b, float gamma, double *losses, uint32_t slot_mask,
                                float loss_scale, const tem_view *db, float grad_scale, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!a || !b || !tem_view_ok(*a) || !tem_view_ok(*b)) return TEM_EINVAL;
   if (!same_extents(*a, *b)) return TEM_ESHAPE;
   V5 d{};
@@ -180,6 +185,7 @@ extern "C" int tem_focal_match(const tem_view *a, const tem_view *b, float gamma
 extern "C" int tem_adam_keras(float *theta, const float *grad, float *m, float *v, int64_t n, float lr, float beta1,
                               float beta2, float eps, float grad_scale, const uint32_t *step_dev,
                               tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!theta || !grad || !m || !v || !step_dev || n < 0) return TEM_EINVAL;
   if (n == 0) return TEM_OK;
   hipLaunchKernelGGL(adam_keras_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, theta, grad, m, v, n, lr,
@@ -189,6 +195,7 @@ extern "C" int tem_adam_keras(float *theta, const float *grad, float *m, float *
 }
 
 extern "C" int tem_step_tick(uint32_t *step_dev, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!step_dev) return TEM_EINVAL;
   hipLaunchKernelGGL(step_tick_k, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
   TEM_CHECK_LAUNCH();
@@ -197,6 +204,7 @@ extern "C" int tem_step_tick(uint32_t *step_dev, tem_stream_t stream) {
 
 extern "C" int tem_u8_to_f32_std(const uint8_t *in, float *out, int64_t n, float mean, float std,
                                  tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!in || !out || n < 0) return TEM_EINVAL;
   if (n == 0) return TEM_OK;
   hipLaunchKernelGGL(u8_to_f32_std_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, mean, std);
@@ -206,6 +214,7 @@ extern "C" int tem_u8_to_f32_std(const uint8_t *in, float *out, int64_t n, float
 
 extern "C" int tem_f32_unstd_to_u8(const tem_view *y, uint8_t *out, int64_t oD, int64_t oH, int64_t oW, float mean,
                                    float std, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!y || !tem_view_ok(*y) || !out) return TEM_EINVAL;
   int64_t total = (int64_t)y->D * y->H * y->W;
   hipLaunchKernelGGL(f32_unstd_to_u8_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dv(*y), out, oD, oH,
@@ -215,6 +224,7 @@ extern "C" int tem_f32_unstd_to_u8(const tem_view *y, uint8_t *out, int64_t oD, 
 }
 
 extern "C" int tem_fill_f32(float *dst, int64_t n, float value, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!dst || n < 0) return TEM_EINVAL;
   if (n == 0) return TEM_OK;
   hipLaunchKernelGGL(fill_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, n, value);
@@ -223,6 +233,7 @@ extern "C" int tem_fill_f32(float *dst, int64_t n, float value, tem_stream_t str
 }
 
 extern "C" int tem_copy_view(const tem_view *src, const tem_view *dst, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!src || !dst || !tem_view_ok(*src) || !tem_view_ok(*dst)) return TEM_EINVAL;
   if (!same_extents(*src, *dst)) return TEM_ESHAPE;
   int64_t total = vtotal(*src);
@@ -233,6 +244,7 @@ extern "C" int tem_copy_view(const tem_view *src, const tem_view *dst, tem_strea
 }
 
 extern "C" int tem_add_view(const tem_view *src, const tem_view *dst, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
   if (!src || !dst || !tem_view_ok(*src) || !tem_view_ok(*dst)) return TEM_EINVAL;
   if (!same_extents(*src, *dst)) return TEM_ESHAPE;
   int64_t total = vtotal(*src);
@@ -243,6 +255,7 @@ extern "C" int tem_add_view(const tem_view *src, const tem_view *dst, tem_stream
 }
 
 extern "C" int tem_abi_version(const char **arch) {
+  TEM_CLEAR_ERR();
   if (arch) *arch = "gfx950";
   return TEM_ABI_VERSION;
 }

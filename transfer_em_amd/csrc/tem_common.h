@@ -10,6 +10,10 @@
     if (e__ != hipSuccess) return (int)e__;        \
   } while (0)
 
+// hipGetLastError() reports the last error of ANY earlier runtime call on this host thread
+// (e.g. a probe inside another library); drop it so that the check after our launch sees only ours.
+#define TEM_CLEAR_ERR() ((void)hipGetLastError())
+
 static inline bool tem_view_ok(const tem_view &v) {
   return v.ptr != nullptr && v.N > 0 && v.D > 0 && v.H > 0 && v.W > 0 && v.C > 0;
 }

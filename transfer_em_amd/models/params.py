@@ -51,14 +51,14 @@ class ParamSet:
         o = self.offsets[name]
         return self.grad[o:o + int(np.prod(self.shapes[name]))]
 
-    def load_dict(self, d):
-        """Load kernels from name -> array (Keras layouts)."""
+    def load_dict(self, d, which="theta"):
+        """Load kernels (or Adam moments: which = "m" / "v") from name -> array (Keras layouts)."""
         host = torch.empty(self.count, dtype=torch.float32)
         for k, s in self.shapes.items():
             a = np.asarray(d[k], np.float32)
             assert tuple(a.shape) == tuple(s), (k, a.shape, s)
             host[self.offsets[k]:self.offsets[k] + a.size] = torch.from_numpy(a.reshape(-1).copy())
-        self.theta.copy_(host)
+        getattr(self, which).copy_(host)
 
     def to_dict(self, which="theta"):
         host = getattr(self, which).detach().cpu().numpy()
