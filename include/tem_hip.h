@@ -119,6 +119,10 @@ int tem_conv_transpose(const tem_conv_args *a, tem_stream_t stream);
 int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream);
 int tem_conv_transpose_direct(const tem_conv_args *a, tem_stream_t stream);
 
+/* 1 if tem_conv / tem_conv_transpose would run these arguments on the LDS/MFMA-tiled kernel,
+ * 0 if on the direct kernel (used by bench.py to label its per-kernel timings). */
+int tem_conv_is_tiled(const tem_conv_args *a, int32_t transposed);
+
 typedef struct tem_bww_args {
   tem_view in0, in1;          /* forward input (concat on C)                           */
   tem_view dout;              /* gradient w.r.t. the pre-activation output             */
@@ -140,10 +144,31 @@ typedef struct tem_bww_args {
  * finishes the sum. */
 int tem_conv_bwd_weight(const tem_bww_args *a, tem_stream_t stream);
 
+/* Workspace sizing: with a->nslab = the largest split the caller is willing to hold, returns the
+ * number of slabs (<= a->nslab) the launch should be given for best occupancy of the 256 CUs
+ * (the LDS-tiled kernel writes one slab per workgroup).  Pass the returned value as nslab to
+ * tem_conv_bwd_weight.  a->slabs may be NULL here.  Negative: TEM_E*. */
+int tem_conv_bwd_weight_nslab(const tem_bww_args *a);
+
 /* out[i] = (accumulate ? out[i] : 0) + scale * sum_s slabs[s*slab_stride + i]
  * (slab_stride 0 == n) */
 int tem_reduce_slabs(const float *slabs, int32_t nslab, int64_t n, int64_t slab_stride,
                      float *out, int32_t accumulate, float scale, tem_stream_t stream);
+
+/* One work item of tem_reduce_slabs_multi: out[i] = scale * sum_{s < nslab} slabs[s*stride + i]
+ * for i < count (count <= 32). */
+typedef struct tem_reduce_item {
+  const float *slabs;
+  int64_t      stride;
+  int32_t      nslab;
+  int32_t      count;
+  float       *out;
+} tem_reduce_item;
+
+/* Finishes the split-K sums of a whole network in ONE launch: `items_dev` is a device array of
+ * `nitems` work items (one workgroup each) covering every kernel of the network. */
+int tem_reduce_slabs_multi(const tem_reduce_item *items_dev, int32_t nitems, float scale,
+                           tem_stream_t stream);
 
 /* out[c] = (accumulate ? out[c] : 0) + sum over all (n,d,h,w) of g[...,c]   (bias gradient,
  * discriminator.py:97-99) */

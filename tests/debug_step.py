@@ -15,8 +15,14 @@ rx, ry = _inputs(shape, 1234), _inputs(shape, 5678)
 st = _state(graph, is3d, True)
 model = EM2EM(n, "dbg", is3d=is3d, seed=42, checkpoint_root="/tmp/dbg_ck")
 _load(model, st)
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+for _ in range(nsteps - 1):
+    model.train_step(torch.from_numpy(rx), torch.from_numpy(ry))
+    graph.train_step(st, rx, ry, is3d, 2.0, 42)
+    _load(model, st)
 got = model.train_step(torch.from_numpy(rx), torch.from_numpy(ry)).cpu().numpy()
 grads_hip = {k: net.params.to_dict("grad") for k, net in zip(("g", "f", "dx", "dy"), model._nets)}
+print("step counters", int(model.step_dev.item()), st["step"])
 losses, grads, aux = graph.train_step(st, rx, ry, is3d, 2.0, 42)
 print("losses", got, losses)
 cs = model._steps[batch]

@@ -1,0 +1,64 @@
+"""Micro-benchmark of single layers (not a test): python tests/microbench.py [layer ...] [--iters N]
+
+Layers: f1 mid d1a u1a d1b (forward), bd_f1 bd_mid bd_d1a (input-gradient), bww_f1 bww_mid bww_d1a bww_f2 bww_c0."""
+import sys, os, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transfer_em_amd import hip_ops as H
+
+H.require_gpu()
+dev = "cuda"
+rnd = lambda *s: torch.randn(*s, device=dev, dtype=torch.float32)
+# name: (CI, CO, k, s, in_edge)
+GEOM = dict(f1=(16, 16, 3, 1, 100), mid=(32, 32, 3, 1, 54), d1a=(8, 8, 3, 1, 130), u1a=(32, 16, 3, 1, 52),
+            d1b=(8, 8, 4, 2, 128), f2=(16, 1, 3, 1, 98), c0=(1, 8, 3, 1, 132))
+
+
+class _P:
+    def __init__(self, shape):
+        self.shapes = {"w": shape}
+        self.grad = torch.zeros(int(np.prod(shape)), dtype=torch.float32, device=dev)
+        self.theta = self.grad
+
+    def g(self, name):
+        return self.grad
+
+
+def build(name, direct=False):
+    kind, layer = ("fwd", name)
+    if name.startswith("bd_"):
+        kind, layer = "bd", name[3:]
+    elif name.startswith("bww_"):
+        kind, layer = "bww", name[4:]
+    CI, CO, k, s, n = GEOM[layer]
+    o = (n - k) // s + 1
+    x, y = rnd(1, n, n, n, CI), rnd(1, o, o, o, CO)
+    w = rnd(k ** 3 * CI * CO) * 0.05
+    if kind == "fwd":
+        return H.conv_launch(name, x, w, y, k, s, 0, slope=0.3, direct=direct)
+    if kind == "bd":
+        return H.conv_launch(name, y, w, x, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI, gate=torch.randn_like(x), direct=direct)
+    ws = H.GradWorkspace(_P((k, k, k, CI, CO)), 1)
+    return H.bww_launch(name, x, y, ws, "w", 0, k, s, 0)
+
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+iters = 20
+for a in sys.argv[1:]:
+    if a.startswith("--iters="):
+        iters = int(a.split("=")[1])
+direct = "--direct" in sys.argv
+for name in args or ["f1"]:
+    l = build(name, direct)
+    s = H.current_stream()
+    for _ in range(3):
+        l(s)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        l(s)
+    b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1e3 / iters
+    print(f"{name:10s} {l.meta['kernel']:36s} {us:9.1f} us  {l.meta['flops'] / us / 1e6:7.2f} TFLOP/s  "
+          f"{l.meta['bytes'] / us / 1e3:8.1f} GB/s")

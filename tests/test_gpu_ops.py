@@ -161,6 +161,25 @@ BWW_CASES = [(1, 8, 3, 1, 0, 14), (8, 8, 3, 1, 0, 12), (8, 8, 4, 2, 0, 14), (8, 
              (32, 32, 1, 1, 0, 6), (32, 1, 1, 1, 0, 6), (1, 8, 3, 1, 4, 8)]
 
 
+class _P:          # minimal stand-in for a ParamSet: one layer "w"
+    def __init__(self, shape):
+        self.shapes = {"w": shape}
+        self.grad = torch.zeros(int(np.prod(shape)), dtype=torch.float32, device="cuda")
+        self.theta = self.grad
+
+    def g(self, name):
+        return self.grad
+
+
+def _bww(H, x, g, shape, k, s=1, pad=0, in1=None, is3d=True):
+    ps = _P(shape)
+    ws = H.GradWorkspace(ps, 2)
+    ws_launch = [H.bww_launch("t0", x, g, ws, "w", 0, k, s, pad, in1=in1, is3d=is3d),
+                 H.bww_launch("t1", x, g, ws, "w", 1, k, s, pad, in1=in1, is3d=is3d)]
+    H.run(ws_launch + ws.reduce_launches("t"))
+    return ps.grad.cpu().numpy().reshape(shape) / 2.0, ws_launch[0].meta["kernel"]
+
+
 @pytest.mark.parametrize("CI,CO,k,s,pad,n", BWW_CASES)
 def test_kernel_gradient(H, oracle_lib, CI, CO, k, s, pad, n):
     rng = np.random.default_rng(CI * 7 + CO)
@@ -168,13 +187,22 @@ def test_kernel_gradient(H, oracle_lib, CI, CO, k, s, pad, n):
     o = [(d + 2 * pad - k) // s + 1 for d in (n, n, n + 1)]
     g = rnd(rng, 2, o[0], o[1], o[2], CO)
     ref = oracle_lib.conv_bwd_weight(x, g, (k, k, k), s, pad)
-    nslab, P = 5, ref.size + 3
-    slabs = torch.full((nslab, P), 7.0, dtype=torch.float32, device="cuda")
-    out = torch.empty(ref.size, dtype=torch.float32, device="cuda")
-    H.run([H.bww_launch("t", dev(x), dev(g), slabs.view(-1)[2:], P, nslab, k, s, pad),
-           H.reduce_slabs_launch("r", slabs.view(-1)[2:], nslab, ref.size, P, out)])
-    assert rel_err(out.cpu().numpy().reshape(ref.shape), ref) < TOL
-    assert float(slabs[:, :2].min()) == 7.0 and float(slabs[:, -1].min()) == 7.0     # nothing written outside
+    got, kern = _bww(H, dev(x), dev(g), ref.shape, k, s, pad)
+    assert rel_err(got, ref) < TOL, kern
+
+
+@pytest.mark.parametrize("CI,CO,k,s,n", [(16, 16, 3, 1, 37), (8, 8, 3, 1, 41), (32, 32, 3, 1, 21), (8, 8, 4, 2, 38),
+                                         (1, 8, 3, 1, 45), (16, 1, 3, 1, 33)])
+def test_kernel_gradient_tiled_multi_segment(H, oracle_lib, CI, CO, k, s, n):
+    """Sizes that give the LDS-tiled kernel several y-chunks and z-segments with ragged ends."""
+    rng = np.random.default_rng(n)
+    x = rnd(rng, 1, n, n - 2, n + 3, CI)
+    o = [(d - k) // s + 1 for d in (n, n - 2, n + 3)]
+    g = rnd(rng, 1, o[0], o[1], o[2], CO)
+    ref = oracle_lib.conv_bwd_weight(x, g, (k, k, k), s, 0)
+    got, kern = _bww(H, dev(x), dev(g), ref.shape, k, s, 0)
+    assert kern.startswith("bww_lds_k")
+    assert rel_err(got, ref) < TOL, kern
 
 
 def test_kernel_gradient_concat_and_transpose_layout(H, oracle_lib):
@@ -182,21 +210,15 @@ def test_kernel_gradient_concat_and_transpose_layout(H, oracle_lib):
     up, skip = rnd(rng, 1, 9, 9, 9, 8), rnd(rng, 1, 12, 12, 12, 8)
     g = rnd(rng, 1, 7, 7, 7, 16)
     ref = oracle_lib.conv_bwd_weight(np.concatenate([up, skip[:, 1:10, 1:10, 1:10]], -1), g, (3, 3, 3))
-    slabs = torch.zeros((4, ref.size), dtype=torch.float32, device="cuda")
-    out = torch.empty(ref.size, dtype=torch.float32, device="cuda")
     sk = dev(skip)
-    H.run([H.bww_launch("t", dev(up), dev(g), slabs.view(-1), ref.size, 4, 3, in1=H.crop(sk, 1, 2)),
-           H.reduce_slabs_launch("r", slabs.view(-1), 4, ref.size, ref.size, out)])
-    assert rel_err(out.cpu().numpy().reshape(ref.shape), ref) < TOL
+    got, _ = _bww(H, dev(up), dev(g), ref.shape, 3, in1=H.crop(sk, 1, 2))
+    assert rel_err(got, ref) < TOL
     # Conv3DTranspose kernel gradient in Keras layout (tap, CO, CI): roles of input / gradient swap
     x = rnd(rng, 1, 6, 6, 6, 16)
     gy = rnd(rng, 1, 12, 12, 12, 8)
     refT = oracle_lib.convT_bwd_weight(x, gy, (4, 4, 4), 2, 1)
-    slabs = torch.zeros((3, refT.size), dtype=torch.float32, device="cuda")
-    out = torch.empty(refT.size, dtype=torch.float32, device="cuda")
-    H.run([H.bww_launch("t", dev(gy), dev(x), slabs.view(-1), refT.size, 3, 4, 2, 1),
-           H.reduce_slabs_launch("r", slabs.view(-1), 3, refT.size, refT.size, out)])
-    assert rel_err(out.cpu().numpy().reshape(refT.shape), refT) < TOL
+    got, _ = _bww(H, dev(gy), dev(x), refT.shape, 4, 2, 1)
+    assert rel_err(got, refT) < TOL
 
 
 def test_losses_and_adam(H, oracle_lib):

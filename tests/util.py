@@ -24,5 +24,10 @@ def scaled_params(shapes, seed, gain=1.0):
         cin = shp[4] if name in ("u2b", "u1b") else shp[3]
         fan_in = taps * cin / (8 if name in ("u2b", "u1b") else 1)     # stride-2 transposed: 1/8 of taps hit
         std = gain * np.sqrt(2.0 / fan_in) / np.sqrt(1 + 0.09)
+        if name == "f2":
+            # keep generator outputs small: the reference's cycle/identity loss is -log(1-|a-b|/2),
+            # whose gradient -1/t blows up as |a-b| -> 2; outputs of O(1) put many voxels next to that
+            # pole and make ANY two float implementations disagree at the 1e-3 level
+            std *= 0.05
         p[name] = (rng.standard_normal(shp) * std).astype(np.float32)
     return p

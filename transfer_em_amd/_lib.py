@@ -56,14 +56,22 @@ class tem_bww_args(C.Structure):
                 ("nslab", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class tem_reduce_item(C.Structure):
+    _fields_ = [("slabs", C.c_void_p), ("stride", C.c_int64), ("nslab", C.c_int32), ("count", C.c_int32),
+                ("out", C.c_void_p)]
+
+
 _VP = C.POINTER(tem_view)
 _SIGS = {
     "tem_conv": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_transpose": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_direct": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_transpose_direct": [C.POINTER(tem_conv_args), C.c_void_p],
+    "tem_conv_is_tiled": [C.POINTER(tem_conv_args), C.c_int32],
     "tem_conv_bwd_weight": [C.POINTER(tem_bww_args), C.c_void_p],
+    "tem_conv_bwd_weight_nslab": [C.POINTER(tem_bww_args)],
     "tem_reduce_slabs": [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p],
+    "tem_reduce_slabs_multi": [C.c_void_p, C.c_int32, C.c_float, C.c_void_p],
     "tem_channel_sum": [_VP, C.c_void_p, C.c_int32, C.c_void_p],
     "tem_focal_logits": [_VP, C.c_int32, C.c_float, C.c_void_p, C.c_uint32, C.c_float, _VP, C.c_float, C.c_void_p],
     "tem_focal_match": [_VP, _VP, C.c_float, C.c_void_p, C.c_uint32, C.c_float, _VP, C.c_float, C.c_void_p],

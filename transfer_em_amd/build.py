@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libtem_hip.so")
-SOURCES = ["conv_direct.hip", "conv_bww.hip", "elementwise.hip", "dispatch.hip"]
+SOURCES = ["conv_direct.hip", "conv_bww.hip", "bww_lds.hip", "conv_lds.hip", "elementwise.hip", "dispatch.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-pass-failed"]
 

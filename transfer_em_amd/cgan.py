@@ -96,27 +96,24 @@ class _CompiledStep:
             H.focal_logits_launch("loss.dy_fake", d_yf.z, 0, gamma, Ls, _bits(L_DISC_Y), 1.0, dz_fy, 1.0),
         ]
 
-        # ---- backward.  Kernel-gradient slabs: one [nslab, P] set per weight-gradient pass.
-        ns = m.nslab
-        sg = torch.zeros((3 * ns, G.params.count), dtype=torch.float32, device=dev)
-        sf = torch.zeros((3 * ns, F.params.count), dtype=torch.float32, device=dev)
-        sdx = torch.zeros((2 * ns, DX.params.count), dtype=torch.float32, device=dev)
-        sdy = torch.zeros((2 * ns, DY.params.count), dtype=torch.float32, device=dev)
-        b_g3 = GenBackward(f_g3, dsame_y, sg[0:ns], **kw)
-        b_f3 = GenBackward(f_f3, dsame_x, sf[0:ns], **kw)
-        b_f2 = GenBackward(f_f2, dcyc_x, sf[ns:2 * ns], need_dx=True, **kw)      # dx = d S / d fake_y (cycle part)
-        b_g2 = GenBackward(f_g2, dcyc_y, sg[ns:2 * ns], need_dx=True, **kw)
+        # ---- backward.  Each weight-gradient pass writes its own partial-sum slabs (GradWorkspace).
+        wg, wf = H.GradWorkspace(G.params, 3), H.GradWorkspace(F.params, 3)
+        wdx, wdy = H.GradWorkspace(DX.params, 2), H.GradWorkspace(DY.params, 2)
+        b_g3 = GenBackward(f_g3, dsame_y, wg, 0, **kw)
+        b_f3 = GenBackward(f_f3, dsame_x, wf, 0, **kw)
+        b_f2 = GenBackward(f_f2, dcyc_x, wf, 1, need_dx=True, **kw)      # dx = d S / d fake_y (cycle part)
+        b_g2 = GenBackward(f_g2, dcyc_y, wg, 1, need_dx=True, **kw)
         # adversarial part through the discriminators (input gradient only), summed onto the cycle part
         a_dy = DiscBackward(d_yf, dz_gen_g, need_dx=True, need_dw=False, **kw)
         a_dx = DiscBackward(d_xf, dz_gen_f, need_dx=True, need_dw=False, **kw)
         add_y = H.copy_view_launch("dfake_y+=adv", a_dy.dx, b_f2.dx, add=True)
         add_x = H.copy_view_launch("dfake_x+=adv", a_dx.dx, b_g2.dx, add=True)
-        b_g1 = GenBackward(f_g1, b_f2.dx, sg[2 * ns:3 * ns], **kw)
-        b_f1 = GenBackward(f_f1, b_g2.dx, sf[2 * ns:3 * ns], **kw)
-        w_dxr = DiscBackward(d_xr, dz_rx, sdx[0:ns], **kw)
-        w_dxf = DiscBackward(d_xf, dz_fx, sdx[ns:2 * ns], **kw)
-        w_dyr = DiscBackward(d_yr, dz_ry, sdy[0:ns], **kw)
-        w_dyf = DiscBackward(d_yf, dz_fy, sdy[ns:2 * ns], **kw)
+        b_g1 = GenBackward(f_g1, b_f2.dx, wg, 2, **kw)
+        b_f1 = GenBackward(f_f1, b_g2.dx, wf, 2, **kw)
+        w_dxr = DiscBackward(d_xr, dz_rx, wdx, 0, **kw)
+        w_dxf = DiscBackward(d_xf, dz_fx, wdx, 1, **kw)
+        w_dyr = DiscBackward(d_yr, dz_ry, wdy, 0, **kw)
+        w_dyf = DiscBackward(d_yf, dz_fy, wdy, 1, **kw)
         self.bwd = dict(g3=b_g3, f3=b_f3, f2=b_f2, g2=b_g2, ady=a_dy, adx=a_dx, g1=b_g1, f1=b_f1,
                         dxr=w_dxr, dxf=w_dxf, dyr=w_dyr, dyf=w_dyf)
         backward = []
@@ -125,14 +122,10 @@ class _CompiledStep:
         backward += [add_y, add_x]
         for p in (b_g1, b_f1, w_dxr, w_dxf, w_dyr, w_dyf):
             backward += p.launches
-        reduce_ = [
-            H.reduce_slabs_launch("grad.g", sg, 3 * ns, G.params.count, G.params.count, G.params.grad),
-            H.reduce_slabs_launch("grad.f", sf, 3 * ns, F.params.count, F.params.count, F.params.grad),
-            H.reduce_slabs_launch("grad.dx", sdx, 2 * ns, DX.params.count, DX.params.count, DX.params.grad),
-            H.reduce_slabs_launch("grad.dy", sdy, 2 * ns, DY.params.count, DY.params.count, DY.params.grad),
-        ]
+        reduce_ = (wg.reduce_launches("g") + wf.reduce_launches("f") + wdx.reduce_launches("dx")
+                   + wdy.reduce_launches("dy"))
         self.compute = forward + loss + backward + reduce_
-        self._keep = (sg, sf, sdx, sdy, dz_gen_g, dz_gen_f, dz_rx, dz_fx, dz_ry, dz_fy, dcyc_x, dcyc_y, dsame_x, dsame_y)
+        self._keep = (wg, wf, wdx, wdy, dz_gen_g, dz_gen_f, dz_rx, dz_fx, dz_ry, dz_fy, dcyc_x, dcyc_y, dsame_x, dsame_y)
 
         # ---- optimizer (cgan.py:218-228); gradients are averaged over ranks by grad_scale
         ws = m.world_size

@@ -138,6 +138,36 @@ __global__ __launch_bounds__(256) void reduce_slabs_k(const float *slabs, int ns
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// One launch finishes the split-K sums of ALL layers of a network: block b reduces items[b]
+// (<= 32 consecutive kernel entries of one layer) over that layer's slabs.  Thread = (entry
+// tid&31, slab lane tid>>5); each lane strides the slabs by 8 with 4 loads in flight, then the
+// 8 lanes are summed through LDS in a fixed order (bitwise reproducible).
+__global__ __launch_bounds__(256) void reduce_multi_k(const tem_reduce_item *items, float scale) {
+  const tem_reduce_item it = items[blockIdx.x];
+  const int pi = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (pi < it.count) {
+    const float *p = it.slabs + pi;
+    int s = sl;
+    for (; s + 24 < it.nslab; s += 32) {
+      s0 += p[(int64_t)s * it.stride];
+      s1 += p[(int64_t)(s + 8) * it.stride];
+      s2 += p[(int64_t)(s + 16) * it.stride];
+      s3 += p[(int64_t)(s + 24) * it.stride];
+    }
+    for (; s < it.nslab; s += 8) s0 += p[(int64_t)s * it.stride];
+  }
+  __shared__ float part[8][32];
+  part[sl][pi] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && pi < it.count) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += part[k][pi];
+    it.out[pi] = v * scale;
+  }
+}
+
 __global__ __launch_bounds__(256) void channel_sum_k(const float *g, int64_t sN, int64_t sD, int64_t sH, int64_t sW,
                                                      int N, int D, int H, int W, int C, float *out, int accumulate) {
   // one block per channel; tensors here are tiny (discriminator logits)
@@ -170,9 +200,26 @@ int launch_bww(const BwwDev &p, hipStream_t st) {
 
 }  // namespace
 
+int tem_bww_lds_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out);   // bww_lds.hip
+
+extern "C" int tem_conv_bwd_weight_nslab(const tem_bww_args *a) {
+  if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout) || a->nslab < 1) return TEM_EINVAL;
+  int n = 0;
+  if (tem_bww_lds_try(a, nullptr, true, &n) == TEM_OK) return n;
+  return a->nslab < 32 ? a->nslab : 32;          // global-load kernel: any split works, 32 is plenty
+}
+
 extern "C" int tem_conv_bwd_weight(const tem_bww_args *a, tem_stream_t stream) {
   TEM_CLEAR_ERR();
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout) || !a->slabs || a->nslab < 1) return TEM_EINVAL;
+  if (a->in0.N != a->dout.N) return TEM_ESHAPE;
+  if (!a->accumulate) {
+    // the tiled kernel writes exactly tem_conv_bwd_weight_nslab(a) slabs; take it only when the
+    // caller sized the workspace with that query (nslab equal), otherwise slabs would be left stale
+    int n = 0;
+    if (tem_bww_lds_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab)
+      return tem_bww_lds_try(a, (hipStream_t)stream, false, nullptr);
+  }
   BwwDev p{};
   const tem_view &i0 = a->in0, &g = a->dout;
   p.in0 = i0.ptr; p.i0N = i0.sN; p.i0D = i0.sD; p.i0H = i0.sH; p.i0W = i0.sW;
@@ -218,6 +265,16 @@ extern "C" int tem_channel_sum(const tem_view *g, float *out, int32_t accumulate
   if (!g || !tem_view_ok(*g) || !out) return TEM_EINVAL;
   hipLaunchKernelGGL(channel_sum_k, dim3(g->C), dim3(256), 0, (hipStream_t)stream, g->ptr, g->sN, g->sD, g->sH,
                      g->sW, g->N, g->D, g->H, g->W, g->C, out, accumulate);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+extern "C" int tem_reduce_slabs_multi(const tem_reduce_item *items_dev, int32_t nitems, float scale,
+                                      tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!items_dev || nitems < 0) return TEM_EINVAL;
+  if (nitems == 0) return TEM_OK;
+  hipLaunchKernelGGL(reduce_multi_k, dim3((unsigned)nitems), dim3(256), 0, (hipStream_t)stream, items_dev, scale);
   TEM_CHECK_LAUNCH();
   return TEM_OK;
 }

@@ -1,0 +1,489 @@
+// conv_lds.hip -- forward / input-gradient convolution of the 3-D layers, LDS-tiled on the
+// fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fmaf chains, no reduced precision).
+//
+//   out[o][co] = epilogue( sum_{tap,ci} X[o*S + tap - P][ci] * W(tap,ci,co) )
+//
+// GEMM view per tap: D[16 voxels][16 co] += A[16 voxels][4 ci] * B[4 ci][16 co].
+//   A comes from an LDS image of the input: channels-last rows with a CI+2 voxel pitch, which
+//     makes the 16-voxel x 2-channel footprint of a ds_read_b32 half-wave hit 32 distinct banks;
+//   B (the kernel taps) is read straight from HBM/L2 into registers, one tap ahead of its use
+//     ([4 ci][16 co] is one contiguous 256-byte run of the Keras kernel layout);
+//   D accumulates in registers and leaves through the fused epilogue (bias, skip-gradient add,
+//     LeakyReLU / LeakyReLU-gradient gate, Philox dropout) as 64-byte channel runs.
+//
+// Data movement: a workgroup owns (n, R output rows, a run of output planes) and marches along
+// z with a ring of K input planes in LDS; per step only the S new planes are fetched (coalesced
+// 16-byte global loads issued before the step's MFMA work, written to LDS after it), so an input
+// voxel is read from HBM/L2 ~(R+K-S)/R times instead of K^3 times, and never re-read for the
+// other output channels.  For stride 1 the R x W output patch is linearised (v = r*WP + x) so
+// that 16-voxel MFMA tiles run across row ends: only the K-1 halo columns per row are wasted.
+// Concat inputs (generator.py:74-86) are gathered by the loader; split outputs are routed by the
+// epilogue; zero padding / cropping is the loader's bounds check.
+//
+// Two waves per SIMD (512-thread workgroups): one wave's loader / epilogue VALU work overlaps the
+// other's MFMA stream.  All index arithmetic is 32-bit (the host checks that every view spans
+// fewer than 2^31 elements).
+#include "tem_common.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+namespace convlds {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Ep32 {                    // epilogue with 32-bit strides
+  const float *bias;
+  float slope;
+  const float *gate; int32_t gN, gD, gH, gW; float gate_slope;
+  const float *add;  int32_t aN, aD, aH, aW, aoz, aoy, aox, aDd, aHh, aWw;
+  int32_t dropout;
+  DropoutStream ds;
+  const uint32_t *step_dev;
+};
+
+struct Dev {
+  const float *in0, *in1;
+  int32_t i0N, i0D, i0H, i0W, i1N, i1D, i1H, i1W;
+  int32_t C0;
+  int32_t N, D, H, W;
+  const float *w;
+  int32_t flip;
+  float *out0, *out1;
+  int32_t o0N, o0D, o0H, o0W, o1N, o1D, o1H, o1W;
+  int32_t CO0;                   // channels routed to out0 (rest to out1)
+  int32_t OD, OH, OW;
+  int32_t P;
+  int32_t R, nych, zsegs, zper;
+  int32_t YR, WX, WP;            // rows per ring slot, voxels loaded per row, LDS row pitch (voxels)
+  int32_t ntiles, nseg;          // m-tiles per z-step; x-segments per row (S == 2 only)
+  uint32_t magicX, magicWP, magicSeg;
+  int32_t chunksX;
+  int32_t dbg;                   // ablation switches (TEM_DEBUG_FLAGS env, perf triage only): 1 no stores, 2 no MFMA, 4 no prefetch
+  Ep32 ep;
+};
+
+template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MTW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
+  constexpr int CIP = CI + 2, NT = (CO + 15) / 16, KS = CI / 4, NTHR = NW * 64, NTAP = K * K * K;
+  static_assert(CI % 8 == 0 && NW % NT == 0, "");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int rowpitch = p.WP * CIP;
+  const int slotpitch = p.YR * rowpitch;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps tile bookkeeping on the scalar unit
+  const int m = lane & 15, kq = lane >> 4;
+
+  int seg = blockIdx.x;
+  const int zseg = seg % p.zsegs; seg /= p.zsegs;
+  const int ych = seg % p.nych;
+  const int n = seg / p.nych;
+  const int oy0 = ych * p.R;
+  const int oz0 = zseg * p.zper;
+  const int oz1 = min(p.OD, oz0 + p.zper);
+  const int nsteps = oz1 - oz0;
+
+  {  // zero the LDS image once: pad voxels and the tail the last tiles over-read stay finite
+    const int total4 = (K * slotpitch + 40 * CIP + 3) / 4;
+    for (int i = tid; i < total4; i += NTHR) reinterpret_cast<float4 *>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+
+  // ---- loader of S new input planes per step (register staged)
+  const int in0_n = n * p.i0N, in1_n = n * p.i1N;
+  const int iy_base = oy0 * S - p.P;
+  auto load_x = [&](float4 (&pf)[MAXPFX], int iz_first, int nplanes) {
+    const int total = nplanes * p.YR * p.chunksX;
+#pragma unroll
+    for (int i = 0; i < MAXPFX; ++i) {
+      int id = tid + i * NTHR;
+      asm volatile("" : "+v"(id));                         // recompute per step: keeps index math out of live registers
+      bool ok = id < total;
+      int rowid = __umulhi((uint32_t)id, p.magicX);
+      int pos = id - rowid * p.chunksX;
+      int pl = rowid >= p.YR ? 1 : 0;
+      int yr = rowid - pl * p.YR;
+      int vox = pos / (CI / 4);
+      int c = (pos - vox * (CI / 4)) * 4;
+      int iz = iz_first + pl, iy = iy_base + yr, ix = vox - p.P;
+      ok = ok && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const float *src = c < p.C0 ? p.in0 + (in0_n + iz * p.i0D + iy * p.i0H + ix * p.i0W + c)
+                                  : p.in1 + (in1_n + iz * p.i1D + iy * p.i1H + ix * p.i1W + (c - p.C0));
+      pf[i] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_x = [&](const float4 (&pf)[MAXPFX], int iz_first, int nplanes) {
+    const int total = nplanes * p.YR * p.chunksX;
+    const int slot0 = ((iz_first % K) + K) % K, slot1 = (slot0 + 1) % K;
+#pragma unroll
+    for (int i = 0; i < MAXPFX; ++i) {
+      int id = tid + i * NTHR;
+      asm volatile("" : "+v"(id));
+      if (id < total) {
+        int rowid = __umulhi((uint32_t)id, p.magicX);
+        int pos = id - rowid * p.chunksX;
+        int pl = rowid >= p.YR ? 1 : 0;
+        int yr = rowid - pl * p.YR;
+        int vox = pos / (CI / 4);
+        int c = (pos - vox * (CI / 4)) * 4;
+        float *d = lds + (pl ? slot1 : slot0) * slotpitch + yr * rowpitch + vox * CIP + c;   // 8-byte aligned
+        *reinterpret_cast<float2 *>(d) = make_float2(pf[i].x, pf[i].y);
+        *reinterpret_cast<float2 *>(d + 2) = make_float2(pf[i].z, pf[i].w);
+      }
+    }
+  };
+
+  // ---- this wave's output tiles: pair index = mtile*NT + nt, dealt round-robin (nt fixed per wave)
+  const int nt = wave % NT;
+  const int npairs = p.ntiles * NT;
+  int abase[MTW];                                        // LDS float index of this lane's A voxel, tap (0,0,0), ci = kq
+#pragma unroll
+  for (int j = 0; j < MTW; ++j) {
+    int pr = min(wave + j * NW, npairs - 1);             // surplus tiles recompute the last one, never stored
+    int t = pr / NT;
+    int vox;
+    if (S == 1) {
+      vox = t * 16 + m;                                  // linearised: v = r*WP + x
+    } else {
+      int r = p.nseg == 1 ? t : (int)__umulhi((uint32_t)t, p.magicSeg), x0 = (t - r * p.nseg) * 16;
+      vox = r * S * p.WP + (x0 + m) * S;
+    }
+    abase[j] = vox * CIP + kq;
+  }
+  // ---- kernel-tap fragment address (lane: ci = 4*s + kq, co = nt*16 + (lane&15))
+  const int co = nt * 16 + m;
+  const bool bvalid = co < CO;
+  const int cob = bvalid ? co : 0;
+  const int bbase = p.flip ? cob * CI + kq : kq * CO + cob;
+  const int bstep = p.flip ? 4 : 4 * CO;                  // per k-step
+  auto load_b = [&](float (&b)[KS], int tap) {
+    const float *wt = p.w + ((p.flip ? NTAP - 1 - tap : tap) * (CI * CO) + bbase);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b[s] = bvalid ? wt[s * bstep] : 0.f;
+  };
+  auto tap_origin = [&](int tap, int izb) -> const float * {
+    const int dz = tap / (K * K), rem = tap - dz * (K * K), dy = rem / K, dx = rem - dy * K;
+    const int slot = (((izb + dz) % K) + K) % K;
+    return lds + (slot * slotpitch + (dy * p.WP + dx) * CIP);
+  };
+
+  // ---- epilogue: lane holds co = nt*16 + m for voxels 4*kq + q of each tile (C/D map)
+  auto epilogue = [&](const f32x4 (&acc)[MTW], int oz) {
+    if (bvalid) {
+      const bool first = co < p.CO0;
+      float *optr = first ? p.out0 + (n * p.o0N + oz * p.o0D + co) : p.out1 + (n * p.o1N + oz * p.o1D + (co - p.CO0));
+      const int oH = first ? p.o0H : p.o1H, oW = first ? p.o0W : p.o1W;
+      const Ep32 &ep = p.ep;
+      const float *gptr = ep.gate ? ep.gate + (n * ep.gN + oz * ep.gD + co) : nullptr;
+      const int az = oz - ep.aoz;
+      const float *aptr = (ep.add && (unsigned)az < (unsigned)ep.aDd) ? ep.add + (n * ep.aN + az * ep.aD + co) : nullptr;
+      const float bias = (ep.bias && first) ? ep.bias[co] : 0.f;
+      DropoutStream ds = ep.ds;
+      if (ep.dropout && ep.step_dev) ds.step = *ep.step_dev;
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) {
+        const int pr = wave + j * NW;
+        if (pr < npairs) {
+          int t = pr / NT;
+          asm volatile("" : "+s"(t));                      // per-step recompute: no hoisted per-tile registers
+          int r, ox;
+          if (S == 1) {
+            const int v = t * 16 + kq * 4;
+            r = __umulhi((uint32_t)v, p.magicWP);
+            ox = v - r * p.WP;
+          } else {
+            r = p.nseg == 1 ? t : (int)__umulhi((uint32_t)t, p.magicSeg);   // magic for d == 1 overflows 32 bits
+            ox = (t - r * p.nseg) * 16 + kq * 4;
+          }
+          uint64_t pblk = ~0ull;
+          Philox128 ph{};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int oy = oy0 + r;
+            if (r < p.R && oy < p.OH && ox < p.OW) {
+              float v = acc[j][q];
+              if (first) {
+                v += bias;
+                if (aptr) {
+                  const int ay = oy - ep.aoy, ax = ox - ep.aox;
+                  if ((unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw) v += aptr[ay * ep.aH + ax * ep.aW];
+                }
+                if (gptr) v = gptr[oy * ep.gH + ox * ep.gW] > 0.f ? v : ep.gate_slope * v;
+                if (DROP && ep.dropout) {
+                  const uint64_t e = ((((uint64_t)n * p.OD + oz) * p.OH + oy) * p.OW + ox) * (uint64_t)p.CO0 + co;
+                  if ((e >> 7) != pblk) { pblk = e >> 7; ph = ds.block(pblk); }
+                  v = DropoutStream::bit(ph, (uint32_t)(e & 127)) ? 2.f * v : 0.f;
+                }
+                if (ep.slope != 1.f) v = v > 0.f ? v : ep.slope * v;
+              }
+              if (!(p.dbg & 1)) optr[oy * oH + ox * oW] = v;
+            }
+            if (S == 1) { if (++ox == p.WP) { ox = 0; ++r; } } else { ++ox; }
+          }
+        }
+      }
+    }
+  };
+
+  float4 pfx[MAXPFX];
+  if (nsteps > 0) {                                        // all K planes of the first step in one flight
+    const int iz0 = oz0 * S - p.P;
+    constexpr int NB = (K + S - 1) / S;
+    float4 pro[NB][MAXPFX];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) load_x(pro[b], iz0 + b * S, min(S, K - b * S));
+#pragma unroll
+    for (int b = 0; b < NB; ++b) store_x(pro[b], iz0 + b * S, min(S, K - b * S));
+  }
+  __syncthreads();
+
+  const bool late = wave >= NW / 2;
+  f32x4 acc_prev[MTW];
+#pragma unroll
+  for (int j = 0; j < MTW; ++j) acc_prev[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int step = 0; step < nsteps; ++step) {
+    const int oz = oz0 + step;
+    const int izb = oz * S - p.P;
+    const bool more = step + 1 < nsteps;
+    if (more && !(p.dbg & 4)) load_x(pfx, izb + K, S);    // next step's HBM/L2 reads fly during the MFMAs
+
+    if (late && step > 0) epilogue(acc_prev, oz - 1);
+
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Flat pipeline over (tap, k-step): the A fragments of the NEXT group are read from LDS before
+    // the current group's MFMAs issue; B fragments of the next tap are fetched one tap ahead.
+    float bcur[KS], bnxt[KS], bnx2[KS];                   // kernel taps: current, +1, +2 (two taps of latency cover)
+    float a0[MTW], a1[MTW];
+    load_b(bcur, 0);
+    load_b(bnxt, NTAP > 1 ? 1 : 0);
+    const float *xt = tap_origin(0, izb);
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) a0[j] = xt[abase[j]];
+    for (int tap = 0; tap < ((p.dbg & 2) ? 1 : NTAP); ++tap) {
+      const int tn = tap + 1 < NTAP ? tap + 1 : tap;
+      const float *xn = tap_origin(tn, izb);
+      load_b(bnx2, tap + 2 < NTAP ? tap + 2 : tap);
+#pragma unroll
+      for (int s = 0; s < KS; s += 2) {
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) a1[j] = xt[abase[j] + (s + 1) * 4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bcur[s], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < KS) {
+#pragma unroll
+          for (int j = 0; j < MTW; ++j) a0[j] = xt[abase[j] + (s + 2) * 4];
+        } else {                                           // first group of the next tap
+#pragma unroll
+          for (int j = 0; j < MTW; ++j) a0[j] = xn[abase[j]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bcur[s + 1], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) { bcur[s] = bnxt[s]; bnxt[s] = bnx2[s]; }
+      xt = xn;
+    }
+
+    // Waves NW/2.. share their SIMDs with waves 0..NW/2-1.  The upper half runs one step's epilogue
+    // (pure VALU + stores) at the START of the next step, i.e. while its SIMD partner streams MFMAs,
+    // and streams its own MFMAs while the partner runs its epilogue: matrix and vector pipes overlap.
+    if (!late) {
+      epilogue(acc, oz);
+    } else {
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) acc_prev[j] = acc[j];
+    }
+    __syncthreads();                                       // all waves are done reading the oldest planes
+    if (more && !(p.dbg & 4)) store_x(pfx, izb + K, S);
+    __syncthreads();
+  }
+  if (late && nsteps > 0) epilogue(acc_prev, oz1 - 1);
+}
+
+// ------------------------------------------------------------------------------------------ host
+constexpr int LDS_BUDGET = 158 * 1024;
+constexpr int TARGET_BLOCKS = 512;
+
+static uint32_t magic_for(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
+
+static bool fits32(const tem_view &v) {
+  int64_t span = (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH +
+                 (int64_t)(v.W - 1) * v.sW + v.C;
+  return span < (int64_t)1 << 31 && v.sN < ((int64_t)1 << 31);
+}
+
+// mode 0: launch; 1: dry run; 2: only predict (*cost receives the model's cycles)
+template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MTW, bool DROP>
+int run(Dev p, hipStream_t st, int mode, double *cost) {
+  constexpr int CIP = CI + 2, NT = (CO + 15) / 16;
+  const int NTHR = NW * 64;
+  p.WX = (p.OW - 1) * S + K;
+  p.WP = p.WX;                                             // LDS row pitch in voxels
+  p.chunksX = p.WX * (CI / 4);
+  p.magicX = magic_for(p.chunksX);
+  p.magicWP = magic_for(p.WP);
+  p.nseg = (p.OW + 15) / 16;
+  p.magicSeg = magic_for(p.nseg);
+  size_t lds_bytes = 0;
+  // Pick rows-per-workgroup R and the z-run length by a small cost model (cycles per SIMD):
+  //   step     = MFMA slots of the two waves sharing a SIMD + loader/epilogue work that does not overlap
+  //   prologue = first K planes + LDS clear, paid once per workgroup
+  //   total    = ceil(workgroups / 256 CUs) * (prologue + steps * step)
+  int R = 0;
+  double best = 1e300;
+  const int NTAPS = K * K * K, KSTEPS = CI / 4;
+  for (int r = 1; r <= (p.OH < 16 ? p.OH : 16); ++r) {
+    int YR = (r - 1) * S + K;
+    int ntiles = S == 1 ? (r * p.WP + 15) / 16 : r * p.nseg;
+    size_t bytes = ((size_t)K * YR * p.WP * CIP + 40 * CIP) * 4;   // + tail the last tiles over-read
+    bool fits = bytes <= (size_t)LDS_BUDGET && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * NTHR &&
+                ntiles * NT <= MTW * NW;
+    if (!fits) continue;
+    int rounds = (ntiles * NT + NW - 1) / NW;                      // tile slots each wave executes per step
+    int nych = (p.OH + r - 1) / r;
+    int cols = p.N * nych;
+    if (rounds > MTW) continue;
+    double step = 2.0 * MTW * NTAPS * KSTEPS * 32.0 * 1.35 + 2500.0 + 600.0 * MTW;   // every wave runs MTW slots
+    double pro = 9000.0 + bytes / 64.0;
+    for (int zs = 1; zs <= p.OD; ++zs) {
+      int zper = (p.OD + zs - 1) / zs, zsegs = (p.OD + zper - 1) / zper;
+      if (zsegs != zs) continue;
+      double t = std::ceil(cols * zsegs / 256.0) * (pro + zper * step);
+      if (t < best) {
+        best = t; R = r; p.R = r; p.YR = YR; p.ntiles = ntiles; lds_bytes = (bytes + 15) & ~(size_t)15;
+        p.nych = nych; p.zper = zper; p.zsegs = zsegs;
+      }
+    }
+  }
+  if (R < 1) return TEM_EUNSUPPORTED;
+  if (cost) *cost = best;
+  if (mode == 2) return TEM_OK;
+  const bool dry = mode == 1;
+  int nblocks = p.N * p.nych * p.zsegs;
+  if (dry) return TEM_OK;
+  if (p.dbg & 8)
+    fprintf(stderr, "conv_lds<%d,%d,%d,%d> OW=%d OH=%d OD=%d: R=%d YR=%d ntiles=%d nych=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI, CO, K, S,
+            p.OW, p.OH, p.OD, p.R, p.YR, p.ntiles, p.nych, p.zsegs, p.zper, nblocks, lds_bytes);
+  auto kern = conv_lds_k<CI, CO, K, S, NW, MAXPFX, MTW, DROP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NTHR), lds_bytes, st, p);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+// each geometry is built with 4 and with 2 (and 1) accumulator tiles per wave; the cost model picks
+template <int CI, int CO, int K, int S, int NW, int MAXPFX, bool DROP>
+int run_best(const Dev &p, hipStream_t st, bool dry) {
+  double c4 = 1e300, c2 = 1e300, c1 = 1e300;
+  run<CI, CO, K, S, NW, MAXPFX, 4, DROP>(p, st, 2, &c4);
+  run<CI, CO, K, S, NW, MAXPFX, 2, DROP>(p, st, 2, &c2);
+  run<CI, CO, K, S, NW, MAXPFX, 1, DROP>(p, st, 2, &c1);
+  if (c4 >= 1e300 && c2 >= 1e300 && c1 >= 1e300) return TEM_EUNSUPPORTED;
+  if (c4 <= c2 && c4 <= c1) return run<CI, CO, K, S, NW, MAXPFX, 4, DROP>(p, st, dry ? 1 : 0, nullptr);
+  if (c2 <= c1) return run<CI, CO, K, S, NW, MAXPFX, 2, DROP>(p, st, dry ? 1 : 0, nullptr);
+  return run<CI, CO, K, S, NW, MAXPFX, 1, DROP>(p, st, dry ? 1 : 0, nullptr);
+}
+
+#define CONV_CASE(ci, co, k, s, nw, pfx, mtw) \
+  if (CI == ci && CO == co && K == k && S == s && !a->ep.dropout) return run_best<ci, co, k, s, nw, pfx, false>(p, st, dry);
+#define CONV_CASE_DROP(ci, co, k, s, nw, pfx, mtw) \
+  if (CI == ci && CO == co && K == k && S == s && a->ep.dropout) return run_best<ci, co, k, s, nw, pfx, true>(p, st, dry);
+
+int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
+  const tem_view &i0 = a->in0, &o0 = a->out0;
+  const bool cube = a->kd == a->kh && a->kh == a->kw && a->sd == a->sh && a->sh == a->sw && a->pd == a->ph &&
+                    a->ph == a->pw;
+  if (!cube || a->kd < 3) return TEM_EUNSUPPORTED;
+  Dev p{};
+  if (!fits32(i0) || !fits32(o0)) return TEM_EUNSUPPORTED;
+  p.in0 = i0.ptr; p.i0N = (int)i0.sN; p.i0D = (int)i0.sD; p.i0H = (int)i0.sH; p.i0W = (int)i0.sW; p.C0 = i0.C;
+  p.in1 = i0.ptr; p.i1N = p.i0N; p.i1D = p.i0D; p.i1H = p.i0H; p.i1W = p.i0W;
+  int CI = i0.C;
+  if (a->in1.ptr) {
+    const tem_view &i1 = a->in1;
+    if (i1.N != i0.N || i1.D != i0.D || i1.H != i0.H || i1.W != i0.W) return TEM_ESHAPE;
+    if (!fits32(i1)) return TEM_EUNSUPPORTED;
+    p.in1 = i1.ptr; p.i1N = (int)i1.sN; p.i1D = (int)i1.sD; p.i1H = (int)i1.sH; p.i1W = (int)i1.sW;
+    CI += i1.C;
+    if (i0.C % 4 || i1.C % 4) return TEM_EUNSUPPORTED;
+  }
+  p.N = i0.N; p.D = i0.D; p.H = i0.H; p.W = i0.W;
+  p.w = a->w; p.flip = a->w_layout == TEM_W_FLIP_CO_CI;
+  p.out0 = o0.ptr; p.o0N = (int)o0.sN; p.o0D = (int)o0.sD; p.o0H = (int)o0.sH; p.o0W = (int)o0.sW; p.CO0 = o0.C;
+  int CO = o0.C;
+  if (a->out1.ptr) {
+    const tem_view &o1 = a->out1;
+    if (o1.N != o0.N || o1.D != o0.D || o1.H != o0.H || o1.W != o0.W) return TEM_ESHAPE;
+    if (!fits32(o1)) return TEM_EUNSUPPORTED;
+    p.out1 = o1.ptr; p.o1N = (int)o1.sN; p.o1D = (int)o1.sD; p.o1H = (int)o1.sH; p.o1W = (int)o1.sW;
+    CO += o1.C;
+  }
+  if (o0.N != i0.N) return TEM_ESHAPE;
+  p.OD = o0.D; p.OH = o0.H; p.OW = o0.W;
+  p.P = a->pd;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
+    p.dbg = dbg;
+  }
+  const tem_epilogue &e = a->ep;
+  Ep32 &q = p.ep;
+  q.bias = e.bias; q.slope = e.slope; q.gate_slope = e.gate_slope;
+  if (e.gate.ptr) {
+    const tem_view &g = e.gate;
+    if (g.N != o0.N || g.D != o0.D || g.H != o0.H || g.W != o0.W || g.C < o0.C) return TEM_ESHAPE;
+    if (!fits32(g)) return TEM_EUNSUPPORTED;
+    q.gate = g.ptr; q.gN = (int)g.sN; q.gD = (int)g.sD; q.gH = (int)g.sH; q.gW = (int)g.sW;
+  }
+  if (e.add.ptr) {
+    const tem_view &ad = e.add;
+    if (ad.C < o0.C || ad.N != o0.N) return TEM_ESHAPE;
+    if (!fits32(ad)) return TEM_EUNSUPPORTED;
+    q.add = ad.ptr; q.aN = (int)ad.sN; q.aD = (int)ad.sD; q.aH = (int)ad.sH; q.aW = (int)ad.sW;
+    q.aoz = e.add_off[0]; q.aoy = e.add_off[1]; q.aox = e.add_off[2];
+    q.aDd = ad.D; q.aHh = ad.H; q.aWw = ad.W;
+  }
+  q.dropout = e.dropout;
+  q.ds.k0 = (uint32_t)e.seed; q.ds.k1 = (uint32_t)(e.seed >> 32); q.ds.site = e.site; q.ds.step = e.step;
+  q.step_dev = e.step_dev;
+  auto aligned = [](const tem_view &v) {
+    return ((uintptr_t)v.ptr & 15) == 0 && v.sW % 4 == 0 && v.sH % 4 == 0 && v.sD % 4 == 0 && v.sN % 4 == 0;
+  };
+  if (!aligned(i0) || (a->in1.ptr && !aligned(a->in1))) return TEM_EUNSUPPORTED;
+  const int K = a->kd, S = a->sd;
+  //         CI  CO  K  S  waves  X-chunks  tiles/wave
+  // (8,8,k3) and (16,8,k3): C_out = 8 fills half of a 16-wide MFMA tile; the direct VALU kernel is
+  // faster there (46 vs 27 TFLOP/s measured on g.d1a) -- they are left to conv_direct.hip.
+  CONV_CASE(8, 16, 3, 1, 8, 5, 8)      // g.d2a, d.hack fwd
+  CONV_CASE(16, 16, 3, 1, 8, 6, 4)     // g.f1 fwd (concat 8+8) and its input-gradient (split 8|8)
+  CONV_CASE(16, 32, 3, 1, 8, 6, 4)     // g.u2a, d.d2a fwd; input-gradient of g.u1a
+  CONV_CASE(32, 16, 3, 1, 8, 6, 4)     // g.u1a fwd; input-gradients of the 16->32 layers
+  CONV_CASE(32, 32, 3, 1, 8, 6, 4)     // g.mid fwd (concat 16+16) and input-gradient (split 16|16); d.d3a
+  CONV_CASE(8, 8, 4, 2, 8, 7, 4)       // g.d1b, d.d1b fwd
+  CONV_CASE(16, 16, 4, 2, 8, 7, 4)     // g.d2b fwd
+  CONV_CASE(32, 32, 4, 2, 8, 7, 4)     // d.d2b, d.d3b fwd
+  CONV_CASE(8, 16, 4, 2, 8, 7, 4)      // input-gradient of the transposed conv g.u1b (k4 s2 p1)
+  CONV_CASE(16, 32, 4, 2, 8, 7, 4)     // input-gradient of g.u2b
+  CONV_CASE_DROP(16, 16, 3, 1, 8, 6, 4)  // input-gradient of g.f1 through Dropout (split 8|8)
+  CONV_CASE_DROP(32, 32, 3, 1, 8, 6, 4)  // input-gradient of g.mid through Dropout (split 16|16)
+  return TEM_EUNSUPPORTED;
+}
+
+}  // namespace convlds
+
+// Called by tem_conv (dispatch.hip) before it falls back to the direct kernel.
+int tem_conv_lds_try(const tem_conv_args *a, hipStream_t st, bool dry) { return convlds::dispatch(a, st, dry); }

@@ -1,11 +1,24 @@
-// dispatch.hip -- public convolution entry points: pick the tiled kernel when the geometry
-// is one it was built for, otherwise the shape-generic direct kernel.
+// dispatch.hip -- public convolution entry points: pick the LDS/MFMA-tiled kernel when the
+// geometry is one it was built for, otherwise the shape-generic direct kernel.
 #include "tem_common.h"
 
+int tem_conv_lds_try(const tem_conv_args *a, hipStream_t st, bool dry);      // conv_lds.hip
+
 extern "C" int tem_conv(const tem_conv_args *a, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (a && tem_view_ok(a->in0) && tem_view_ok(a->out0) && a->w) {
+    int rc = tem_conv_lds_try(a, (hipStream_t)stream, false);
+    if (rc != TEM_EUNSUPPORTED) return rc;
+  }
   return tem_conv_direct(a, stream);
 }
 
 extern "C" int tem_conv_transpose(const tem_conv_args *a, tem_stream_t stream) {
   return tem_conv_transpose_direct(a, stream);
+}
+
+extern "C" int tem_conv_is_tiled(const tem_conv_args *a, int32_t transposed) {
+  if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->out0) || !a->w) return TEM_EINVAL;
+  if (transposed) return 0;
+  return tem_conv_lds_try(a, nullptr, true) == TEM_OK ? 1 : 0;
 }

@@ -125,18 +125,63 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
     ntap = a.kd * a.kh * a.kw
     vin, vout = in0.numel() // ci0, out0.numel() // co0
     ci, co = ci0 + ci1, co0 + co1
+    tiled = (not direct) and lib.tem_conv_is_tiled(C.byref(a), int(transposed)) == 1
+    if tiled:
+        kern = f"conv_lds_k<{ci}, {co}, {k}, {s}>"
+    elif transposed:
+        kern = f"convT_direct_k<{ci0}, {co0}, {co1}>"
+    else:
+        kern = f"conv_direct_k<{ci0}, {ci1}, {co0}, {co1}, {'true' if layout == TEM_W_FLIP_CO_CI else 'false'}>"
     meta = dict(flops=2.0 * ntap * ci * co * (vin if transposed else vout),
-                bytes=4.0 * (ci * vin + co * vout + ntap * ci * co),
-                kernel=(f"convT_direct_k<{ci0}, {co0}, {co1}>" if transposed else
-                        f"conv_direct_k<{ci0}, {ci1}, {co0}, {co1}, {'true' if layout == TEM_W_FLIP_CO_CI else 'false'}>"))
+                bytes=4.0 * (ci * vin + co * vout + ntap * ci * co), kernel=kern)
     return Launch(fn, (C.byref(a),), name, keep + [a], meta)
 
 
-def bww_launch(name, in0, dout, slabs, slab_stride, nslab, k, s=1, p=0, *, is3d=True, in1=None, accumulate=False):
-    """Kernel-gradient launch; `slabs` is the 1-D float32 tensor slice where slab 0 starts."""
+MAX_SLABS = 1024
+
+
+class GradWorkspace:
+    """Kernel-gradient partial sums of one network: per layer a dense [ncalls, nslab, size] tensor.
+
+    Every weight-gradient pass (`call`) of a step writes its own slab set, so passes may run
+    concurrently; `reduce_launches()` sums calls x slabs into the network's flat gradient vector.
+    The slab count per layer comes from the library (tem_conv_bwd_weight_nslab)."""
+
+    def __init__(self, params, ncalls):
+        self.params, self.ncalls, self.buf = params, ncalls, {}
+
+    def slabs(self, layer, call, nslab):
+        size = 1
+        for d in self.params.shapes[layer]:
+            size *= d
+        t = self.buf.get(layer)
+        if t is None:
+            t = self.buf[layer] = torch.zeros((self.ncalls, nslab, size), dtype=torch.float32,
+                                              device=self.params.theta.device)
+        assert t.shape[1] == nslab, (layer, t.shape, nslab)
+        return t[call]
+
+    def reduce_launches(self, prefix):
+        """ONE launch summing calls x slabs of every layer into the flat gradient vector."""
+        lib = _lib.load()
+        items = []
+        for layer, t in self.buf.items():
+            n, nsl = t.shape[2], t.shape[0] * t.shape[1]
+            out = self.params.g(layer)
+            for o in range(0, n, 32):
+                items.append((t.data_ptr() + 4 * o, n, nsl, min(32, n - o), out.data_ptr() + 4 * o))
+        arr = (_lib.tem_reduce_item * len(items))(*[_lib.tem_reduce_item(*it) for it in items])
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        table = host.to(self.params.theta.device)
+        return [Launch(lib.tem_reduce_slabs_multi, (table.data_ptr(), len(items), 1.0), f"{prefix}.reduce",
+                       [table, self], dict(kernel="reduce_multi_k"))]
+
+
+def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=None):
+    """Kernel-gradient launch of `layer` into its slab set `call` of GradWorkspace `ws`."""
     lib = _lib.load()
     a = tem_bww_args()
-    keep = [in0, dout, slabs]
+    keep = [in0, dout]
     a.in0 = view(in0)
     if in1 is not None:
         a.in1 = view(in1); keep.append(in1)
@@ -144,17 +189,24 @@ def bww_launch(name, in0, dout, slabs, slab_stride, nslab, k, s=1, p=0, *, is3d=
     a.kd, a.kh, a.kw = _k3(k, is3d)
     a.sd, a.sh, a.sw = _s3(s, is3d)
     a.pd, a.ph, a.pw = _p3(p, is3d)
+    a.nslab = MAX_SLABS
+    n = lib.tem_conv_bwd_weight_nslab(C.byref(a))
+    if n < 1:
+        _lib.check(n, name + " (nslab query)")
+    slabs = ws.slabs(layer, call, n)
+    keep.append(slabs)
     a.slabs = slabs.data_ptr()
-    a.slab_stride = slab_stride
-    a.nslab = nslab
-    a.accumulate = int(accumulate)
+    a.slab_stride = 0
+    a.nslab = n
+    a.accumulate = 0
     ci = in0.shape[4] + (in1.shape[4] if in1 is not None else 0)
     co = dout.shape[4]
     ntap = a.kd * a.kh * a.kw
     vin, vout = in0.numel() // in0.shape[4], dout.numel() // co
+    tiled = is3d and k >= 3 and not (k == 4 and ci == 32 and co == 32)
     mt = 6 if ci >= 32 else (3 if ci >= 16 else 2)
     meta = dict(flops=2.0 * ntap * ci * co * vout, bytes=4.0 * (ci * vin + co * vout + ntap * ci * co),
-                kernel=f"bww_mfma_k<{mt}, {2 if co > 16 else 1}>")
+                kernel=(f"bww_lds_k<{ci}, {co}, {k}, {s}, 4>" if tiled else f"bww_mfma_k<{mt}, {2 if co > 16 else 1}>"))
     return Launch(lib.tem_conv_bwd_weight, (C.byref(a),), name, keep + [a], meta)
 
 

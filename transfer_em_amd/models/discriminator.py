@@ -96,16 +96,13 @@ class DiscBackward:
     """Adjoint of a DiscForward for one upstream gradient dz.  need_dw=False is the
     generator's adversarial path (input gradient only, cgan.py:192-193,207-210)."""
 
-    def __init__(self, fwd, dz, slabs=None, need_dx=False, need_dw=True, direct=False):
+    def __init__(self, fwd, dz, ws=None, call=0, need_dx=False, need_dw=True, direct=False):
         net, A = fwd.net, fwd.act
         P, is3d = net.params, net.is3d
         self.fwd, self.dz = fwd, dz
         order = fwd.order
         G = self.grads = {k: torch.empty_like(A[k]) for k in order[:-1]}
         self.dx = torch.empty_like(fwd.x) if need_dx else None
-        if need_dw:
-            nslab, stride = slabs.shape
-            flat = slabs.view(-1)
         L = self.launches = []
         g_out = dz
         for i in range(len(order) - 1, -1, -1):
@@ -114,10 +111,9 @@ class DiscBackward:
             i3 = is3d if k > 1 else True
             xin = A[order[i - 1]] if i > 0 else fwd.x
             if need_dw:
-                L.append(H.bww_launch("d.bww." + name, xin, g_out, flat[P.offsets[name]:], stride, nslab, k, s, 0,
-                                      is3d=i3))
+                L.append(H.bww_launch("d.bww." + name, xin, g_out, ws, name, call, k, s, 0, is3d=i3))
                 if name == "p2":
-                    L.append(H.channel_sum_launch("d.bias", g_out, flat[P.offsets["p2_bias"]:]))
+                    L.append(H.channel_sum_launch("d.bias", g_out, ws.slabs("p2_bias", call, 1).view(-1)))
             if i == 0 and not need_dx:
                 break
             dst = G[order[i - 1]] if i > 0 else self.dx

@@ -120,13 +120,11 @@ class GenForward:
 class GenBackward:
     """Adjoint of one GenForward: fills this call's kernel-gradient slabs and, if asked, dx."""
 
-    def __init__(self, fwd, dy, slabs, need_dx=False, direct=False):
+    def __init__(self, fwd, dy, ws, call, need_dx=False, direct=False):
         net, A, e = fwd.net, fwd.act, fwd.edges
         P, is3d = net.params, net.is3d
         N, dev = fwd.x.shape[0], fwd.x.device
-        self.fwd, self.dy, self.slabs = fwd, dy, slabs
-        nslab, stride = slabs.shape[0], slabs.shape[1]
-        flat = slabs.view(-1)
+        self.fwd, self.dy = fwd, dy
         ch = {k: s[-1] for k, s in P.shapes.items()}
         ch["u2b"], ch["u1b"] = P.shapes["u2b"][3], P.shapes["u1b"][3]
 
@@ -147,8 +145,7 @@ class GenBackward:
         cv = H.conv_launch
 
         def bww(name, in0, dout, k, s=1, p=0, in1=None):
-            return H.bww_launch("g.bww." + name, in0, dout, flat[P.offsets[name]:], stride, nslab, k, s, p, is3d=is3d,
-                                in1=in1)
+            return H.bww_launch("g.bww." + name, in0, dout, ws, name, call, k, s, p, is3d=is3d, in1=in1)
 
         L = self.launches = []
         L.append(bww("f2", A["f1"], dy, 3))
