@@ -1,0 +1,58 @@
+"""No-GPU tests of the host side of the mirror: shape algebra, dataset pipeline, tiling plan."""
+import numpy as np
+import pytest
+
+
+def test_shape_algebra_matches_reference_comments():
+    from transfer_em_amd.models.generator import (generator_edges, generator_out, skip_crop, generator_param_shapes,
+                                                  VALID_DIMS)
+    from transfer_em_amd.models.discriminator import discriminator_edges, discriminator_param_shapes
+    assert list(generator_edges(74).values()) == [74, 72, 70, 34, 32, 15, 13, 26, 24, 22, 44, 42, 40]
+    assert generator_out(132) == 96 and 74 in VALID_DIMS and 132 in VALID_DIMS
+    assert skip_crop(61, 54) == (3, 4)
+    assert sum(int(np.prod(s)) for s in generator_param_shapes(True).values()) == 129480
+    assert sum(int(np.prod(s)) for s in discriminator_param_shapes(True).values()) == 181369
+    assert discriminator_edges(96)["p2"] == 8 and discriminator_edges(40)["p2"] == 1
+    assert discriminator_edges(96, False)["p2"] == 20 and discriminator_edges(40, False)["p2"] == 6
+    from oracle import graph                       # the product and the oracle state the same algebra independently
+    for n in (74, 132, 260):
+        assert list(generator_edges(n).values()) == list(graph.generator_edges(n).values())
+    assert dict(generator_param_shapes(False)) == dict(graph.generator_param_shapes(False))
+    assert dict(discriminator_param_shapes(True)) == dict(graph.discriminator_param_shapes(True))
+
+
+def test_dataset_pipeline():
+    from transfer_em_amd.datasets import datasets as D
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, (128, 128), dtype=np.uint8) for _ in range(5)]
+    ds, ms = D.create_dataset_from_tensors(imgs, batch_size=2, padding=[[2, 2], [2, 2]], enable_augmentation=False)
+    assert len(ds) == 2                                           # drop_remainder
+    b = next(iter(ds))
+    assert b.shape == (2, 132, 132, 1) and b.dtype == np.float32  # simple_training.ipynb: 128 -> 132 by REFLECT
+    scaled = [np.pad(i, 2, mode="reflect").astype(np.float32) / 127.5 - 1 for i in imgs]
+    assert abs(ms[0] - np.mean([s.mean() for s in scaled])) < 1e-6
+    assert abs(ms[1] - np.sqrt(np.mean([s.var() for s in scaled]))) < 1e-6
+    assert np.allclose(b[0, ..., 0], (scaled[0] - ms[0]) / ms[1], atol=1e-5)
+    assert np.allclose(D.unstandardize_population(b, ms)[0, ..., 0], scaled[0], atol=1e-5)
+    ds2, ms2 = D.create_dataset_from_tensors(imgs, batch_size=2, meanstd=ms, enable_augmentation=True, seed=3)
+    a1 = [x.copy() for x in ds2]
+    ds3, _ = D.create_dataset_from_tensors(imgs, batch_size=2, meanstd=ms, enable_augmentation=True, seed=3)
+    assert all(np.array_equal(p, q) for p, q in zip(a1, ds3))     # seeded augmentation is reproducible
+    gen = (rng.integers(0, 256, (8, 8, 8), dtype=np.uint8) for _ in iter(int, 1))
+    dsg, _ = D.create_dataset_from_generator(gen, batch_size=1, epoch_size=3)
+    assert len(dsg) == 3 and next(iter(dsg)).shape == (1, 8, 8, 8, 1)
+
+
+def test_tile_plan_matches_reference_logic():
+    from transfer_em_amd.utils import tile_plan
+    # dimsize 132: out 96, buffer 18, 96 % 6 == 0 -> no tpad; 260^3 request -> 27 tiles
+    out, buf, tpad, rois, index = tile_plan((0, 0, 0), (260, 260, 260), 96, 18)
+    assert (out, buf, tpad, len(rois)) == (96, 18, 0, 27) and rois[0] == (-18, -18, -18) and index[-1] == (192, 192, 192)
+    # dimsize 74: out 40 -> 36 with tpad 2, buffer 17 -> 19, tile input 74
+    out, buf, tpad, rois, _ = tile_plan((10, 20, 30), (72, 72, 72), 40, 17)
+    assert (out, buf, tpad, len(rois)) == (36, 19, 2, 8) and out + 2 * buf == 74 and rois[0] == (-9, 1, 11)
+
+
+def test_shard_helpers():
+    from transfer_em_amd import distributed as D
+    assert D.shard(range(7), 1, 3) == [1, 4] and D.replica_seed(42, 3) == 45

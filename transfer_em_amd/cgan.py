@@ -22,6 +22,7 @@ import time
 import numpy as np
 import torch
 
+from . import distributed as D
 from . import hip_ops as H
 from .debug import accuracy, generate_images
 from .models.discriminator import *   # noqa: F401,F403  (reference does the same star imports)
@@ -155,7 +156,7 @@ class EM2EM(object):
         self.pg = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if self._dist() else 1
         self.rank = torch.distributed.get_rank(process_group) if self._dist() else 0
-        self.seed = int(seed) + self.rank            # independent dropout stream per replica
+        self.seed = D.replica_seed(seed, self.rank)  # independent dropout stream per replica
 
         sd = weight_seeds
         self.discriminator_x = discriminator(is3d, norm_type=norm_type, wf=wf, device=self.device, seed=sd[2])
@@ -260,7 +261,7 @@ class EM2EM(object):
         st.losses.zero_()
         H.run(st.compute, s)
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.grad_all, group=self.pg)       # RCCL over xGMI (sum; Adam scales)
+            D.allreduce_sum_(self.grad_all, self.pg)     # RCCL over xGMI (sum; the Adam kernel scales by 1/world)
         H.run(st.update, s)
         return st.losses[:7].to(torch.float32)
 
