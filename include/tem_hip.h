@@ -119,9 +119,10 @@ int tem_conv_transpose(const tem_conv_args *a, tem_stream_t stream);
 int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream);
 int tem_conv_transpose_direct(const tem_conv_args *a, tem_stream_t stream);
 
-/* 1 if tem_conv / tem_conv_transpose would run these arguments on the LDS/MFMA-tiled kernel,
- * 0 if on the direct kernel (used by bench.py to label its per-kernel timings). */
-int tem_conv_is_tiled(const tem_conv_args *a, int32_t transposed);
+/* 1 if tem_conv / tem_conv_transpose would run these arguments on the LDS/MFMA-tiled kernel
+ * (then `name`, if non-NULL, receives the kernel's template name as rocprofv3 prints it), 0 if
+ * on the direct kernel.  Used by bench.py to label its per-kernel timings. */
+int tem_conv_is_tiled(const tem_conv_args *a, int32_t transposed, char *name, int32_t name_len);
 
 typedef struct tem_bww_args {
   tem_view in0, in1;          /* forward input (concat on C)                           */
@@ -149,6 +150,9 @@ int tem_conv_bwd_weight(const tem_bww_args *a, tem_stream_t stream);
  * (the LDS-tiled kernel writes one slab per workgroup).  Pass the returned value as nslab to
  * tem_conv_bwd_weight.  a->slabs may be NULL here.  Negative: TEM_E*. */
 int tem_conv_bwd_weight_nslab(const tem_bww_args *a);
+
+/* Same as tem_conv_is_tiled for tem_conv_bwd_weight (a->nslab must be the value the launch will use). */
+int tem_bww_is_tiled(const tem_bww_args *a, char *name, int32_t name_len);
 
 /* out[i] = (accumulate ? out[i] : 0) + scale * sum_s slabs[s*slab_stride + i]
  * (slab_stride 0 == n) */

@@ -67,7 +67,8 @@ _SIGS = {
     "tem_conv_transpose": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_direct": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_transpose_direct": [C.POINTER(tem_conv_args), C.c_void_p],
-    "tem_conv_is_tiled": [C.POINTER(tem_conv_args), C.c_int32],
+    "tem_conv_is_tiled": [C.POINTER(tem_conv_args), C.c_int32, C.c_char_p, C.c_int32],
+    "tem_bww_is_tiled": [C.POINTER(tem_bww_args), C.c_char_p, C.c_int32],
     "tem_conv_bwd_weight": [C.POINTER(tem_bww_args), C.c_void_p],
     "tem_conv_bwd_weight_nslab": [C.POINTER(tem_bww_args)],
     "tem_reduce_slabs": [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p],

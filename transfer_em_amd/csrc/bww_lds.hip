@@ -17,6 +17,7 @@
 // Both MFMA fragments are plain ds_read_b32: A = [4 voxels][16 (tap,ci) rows], B = [4 voxels]
 // [16 co] -- the channels-last layout as it is.
 #include "tem_common.h"
+#include <cstdio>
 
 namespace bwwlds {
 
@@ -302,6 +303,8 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
 
 // ------------------------------------------------------------------------------------------ host
 constexpr int LDS_BUDGET = 150 * 1024;
+static thread_local char *g_name = nullptr;
+static thread_local int g_name_len = 0;
 constexpr int TARGET_BLOCKS = 512;
 
 static uint32_t magic_for(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
@@ -345,7 +348,10 @@ int run(Dev &p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   int nblocks = 0;
   if (!plan<CI, CO, K, S, NW, MAXPFX, MAXPFG>(p, max_slabs, lds_bytes, nblocks)) return TEM_EUNSUPPORTED;
   if (nslab_out) *nslab_out = nblocks;
-  if (dry) return TEM_OK;
+  if (dry) {
+    if (g_name) snprintf(g_name, g_name_len, "bww_lds_k<%d, %d, %d, %d, %d, %d, %d>", CI, CO, K, S, NW, MAXPFX, MAXPFG);
+    return TEM_OK;
+  }
   auto kern = bww_lds_k<CI, CO, K, S, NW, MAXPFX, MAXPFG>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -399,7 +405,8 @@ int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
   BWW_CASE(16, 32, 3, 1, 4, 8, 5)    // g.u2a / d.d2a: 54 tiles
   BWW_CASE(32, 32, 3, 1, 8, 5, 3)    // g.mid / d.d3a: 108 tiles, 14 per wave
   BWW_CASE(32, 16, 3, 1, 8, 5, 3)    // g.u1a: 54 tiles
-  BWW_CASE(16, 1, 3, 1, 4, 8, 5)     // g.f2
+  BWW_CASE(16, 1, 3, 1, 4, 8, 5)     // (kept for callers that do not use the swapped C_out = 1 form)
+  BWW_CASE(1, 16, 3, 1, 4, 6, 8)     // g.f2 swapped: X := dy (1 ch), G := f1 (16 ch), pad 2 -> dW with flipped taps
   BWW_CASE(8, 8, 4, 2, 4, 12, 3)     // g.d1b / d.d1b: 32 tiles
   BWW_CASE(16, 16, 4, 2, 8, 6, 3)    // g.d2b: 64 tiles
   BWW_CASE(8, 16, 4, 2, 4, 12, 4)    // g.u1b (transposed conv: roles of input and gradient swapped)
@@ -414,4 +421,12 @@ int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
 // Called by tem_conv_bwd_weight (conv_bww.hip) before it falls back to the global-load kernel.
 int tem_bww_lds_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
   return bwwlds::dispatch(a, st, dry, nslab_out);
+}
+
+int tem_bww_lds_describe(const tem_bww_args *a, char *buf, int len) {
+  bwwlds::g_name = buf; bwwlds::g_name_len = len;
+  int n = 0;
+  int rc = bwwlds::dispatch(a, nullptr, true, &n);
+  bwwlds::g_name = nullptr;
+  return rc == TEM_OK && n == a->nslab ? TEM_OK : TEM_EUNSUPPORTED;
 }

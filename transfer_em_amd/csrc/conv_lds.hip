@@ -311,6 +311,8 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
 
 // ------------------------------------------------------------------------------------------ host
 constexpr int LDS_BUDGET = 158 * 1024;
+static thread_local char *g_name = nullptr;   // set by tem_conv_describe around a dry run
+static thread_local int g_name_len = 0;
 constexpr int TARGET_BLOCKS = 512;
 
 static uint32_t magic_for(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
@@ -369,7 +371,12 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
   if (mode == 2) return TEM_OK;
   const bool dry = mode == 1;
   int nblocks = p.N * p.nych * p.zsegs;
-  if (dry) return TEM_OK;
+  if (dry) {
+    if (g_name)
+      snprintf(g_name, g_name_len, "conv_lds_k<%d, %d, %d, %d, %d, %d, %d, %s>", CI, CO, K, S, NW, MAXPFX, MTW,
+               DROP ? "true" : "false");
+    return TEM_OK;
+  }
   if (p.dbg & 8)
     fprintf(stderr, "conv_lds<%d,%d,%d,%d> OW=%d OH=%d OD=%d: R=%d YR=%d ntiles=%d nych=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI, CO, K, S,
             p.OW, p.OH, p.OD, p.R, p.YR, p.ntiles, p.nych, p.zsegs, p.zper, nblocks, lds_bytes);
@@ -487,3 +494,10 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
 
 // Called by tem_conv (dispatch.hip) before it falls back to the direct kernel.
 int tem_conv_lds_try(const tem_conv_args *a, hipStream_t st, bool dry) { return convlds::dispatch(a, st, dry); }
+
+int tem_conv_lds_describe(const tem_conv_args *a, char *buf, int len) {
+  convlds::g_name = buf; convlds::g_name_len = len;
+  int rc = convlds::dispatch(a, nullptr, true);
+  convlds::g_name = nullptr;
+  return rc;
+}

@@ -125,9 +125,10 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
     ntap = a.kd * a.kh * a.kw
     vin, vout = in0.numel() // ci0, out0.numel() // co0
     ci, co = ci0 + ci1, co0 + co1
-    tiled = (not direct) and lib.tem_conv_is_tiled(C.byref(a), int(transposed)) == 1
+    namebuf = C.create_string_buffer(96)
+    tiled = (not direct) and lib.tem_conv_is_tiled(C.byref(a), int(transposed), namebuf, 96) == 1
     if tiled:
-        kern = f"conv_lds_k<{ci}, {co}, {k}, {s}>"
+        kern = namebuf.value.decode()
     elif transposed:
         kern = f"convT_direct_k<{ci0}, {co0}, {co1}>"
     else:
@@ -149,6 +150,7 @@ class GradWorkspace:
 
     def __init__(self, params, ncalls):
         self.params, self.ncalls, self.buf = params, ncalls, {}
+        self.flip_rows = {}        # layer -> row length: slab rows are stored in reversed tap order
 
     def slabs(self, layer, call, nslab):
         size = 1
@@ -168,6 +170,12 @@ class GradWorkspace:
         for layer, t in self.buf.items():
             n, nsl = t.shape[2], t.shape[0] * t.shape[1]
             out = self.params.g(layer)
+            row = self.flip_rows.get(layer)
+            if row:                 # C_out == 1 layers computed in swapped form: slab row r holds tap (ntap-1-r)
+                assert row <= 32 and n % row == 0
+                for r in range(n // row):
+                    items.append((t.data_ptr() + 4 * r * row, n, nsl, row, out.data_ptr() + 4 * (n // row - 1 - r) * row))
+                continue
             for o in range(0, n, 32):
                 items.append((t.data_ptr() + 4 * o, n, nsl, min(32, n - o), out.data_ptr() + 4 * o))
         arr = (_lib.tem_reduce_item * len(items))(*[_lib.tem_reduce_item(*it) for it in items])
@@ -180,6 +188,13 @@ class GradWorkspace:
 def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=None):
     """Kernel-gradient launch of `layer` into its slab set `call` of GradWorkspace `ws`."""
     lib = _lib.load()
+    if is3d and dout.shape[4] == 1 and in1 is None and s == 1 and p == 0 and k == 3 and in0.shape[4] % 16 == 0:
+        # C_out == 1 (generator.py:110): a 1-wide N would waste 15/16 of every MFMA.  Swap the roles:
+        #   dW[tap][ci] = sum_v X[v+tap][ci] g[v] = sum_v' g[v' - tap] X[v'][ci]
+        # i.e. the kernel gradient of a pad-(k-1) conv with input g (1 channel) and "gradient" X, whose
+        # taps come out reversed; the slab reduction un-reverses them (GradWorkspace.flip_rows).
+        ws.flip_rows[layer] = in0.shape[4]
+        in0, dout, p = dout, in0, k - 1
     a = tem_bww_args()
     keep = [in0, dout]
     a.in0 = view(in0)
@@ -203,10 +218,11 @@ def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=
     co = dout.shape[4]
     ntap = a.kd * a.kh * a.kw
     vin, vout = in0.numel() // in0.shape[4], dout.numel() // co
-    tiled = is3d and k >= 3 and not (k == 4 and ci == 32 and co == 32)
+    namebuf = C.create_string_buffer(96)
+    tiled = lib.tem_bww_is_tiled(C.byref(a), namebuf, 96) == 1
     mt = 6 if ci >= 32 else (3 if ci >= 16 else 2)
     meta = dict(flops=2.0 * ntap * ci * co * vout, bytes=4.0 * (ci * vin + co * vout + ntap * ci * co),
-                kernel=(f"bww_lds_k<{ci}, {co}, {k}, {s}, 4>" if tiled else f"bww_mfma_k<{mt}, {2 if co > 16 else 1}>"))
+                kernel=(namebuf.value.decode() if tiled else f"bww_mfma_k<{mt}, {2 if co > 16 else 1}>"))
     return Launch(lib.tem_conv_bwd_weight, (C.byref(a),), name, keep + [a], meta)
 
 
