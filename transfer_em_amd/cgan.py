@@ -123,10 +123,29 @@ class _CompiledStep:
         backward += [add_y, add_x]
         for p in (b_g1, b_f1, w_dxr, w_dxf, w_dyr, w_dyf):
             backward += p.launches
-        reduce_ = (wg.reduce_launches("g") + wf.reduce_launches("f") + wdx.reduce_launches("dx")
-                   + wdy.reduce_launches("dy"))
-        self.compute = forward + loss + backward + reduce_
+        red = {k: w.reduce_launches(k) for k, w in (("g", wg), ("f", wf), ("dx", wdx), ("dy", wdy))}
+        reduce_ = red["g"] + red["f"] + red["dx"] + red["dy"]
+        self.compute = forward + loss + backward + reduce_          # flat order (single stream, profiling)
         self._keep = (wg, wf, wdx, wdy, dz_gen_g, dz_gen_f, dz_rx, dz_fx, dz_ry, dz_fy, dcyc_x, dcyc_y, dsame_x, dsame_y)
+
+        # ---- two-stream schedule.  The discriminators' layers are small (20^3 .. 8^3 voxels deep in the
+        # stack) and cannot fill 256 CUs; they run on a side stream beside the generators' large kernels:
+        #   main: G/F forwards -> cycle/identity losses -> generator sweep -> G/F gradient reduction
+        #   side: D(real) | after fake_*: D(fake) -> adversarial + discriminator losses -> input-gradient of
+        #         the adversarial term (joined into the generator sweep) -> discriminator sweep -> reduction
+        L_ = lambda *plans: [l for pl in plans for l in pl.launches]
+        main, side = [], []
+        side += [("wait", "inputs")] + L_(d_xr, d_yr)
+        main += L_(f_g1) + [("record", "fake_y")] + L_(f_f2, f_f1) + [("record", "fake_x")] + L_(f_g2, f_f3, f_g3)
+        side += [("wait", "fake_y")] + L_(d_yf) + [("wait", "fake_x")] + L_(d_xf)
+        side += [loss[0], loss[1]] + loss[6:10] + L_(a_dy, a_dx) + [("record", "adv")]
+        side += L_(w_dxr, w_dxf, w_dyr, w_dyf) + red["dx"] + red["dy"]
+        side += [("record", "side_done")]
+        main += loss[2:6] + L_(b_g3, b_f3, b_f2, b_g2) + [("wait", "adv"), add_y, add_x] + L_(b_g1, b_f1)
+        main += red["g"] + red["f"] + [("wait", "side_done")]
+        self.main, self.side = main, side
+        self.side_stream = torch.cuda.Stream(device=dev)
+        self.events = {k: torch.cuda.Event() for k in ("inputs", "fake_y", "fake_x", "adv", "side_done")}
 
         # ---- optimizer (cgan.py:218-228); gradients are averaged over ranks by grad_scale
         ws = m.world_size
@@ -146,13 +165,14 @@ class EM2EM(object):
 
     def __init__(self, dimsize, exp_name, is3d=True, norm_type="instancenorm", ckpt_restore=None, wf=8,
                  focal_gamma=2, disc_prior=None, device=None, seed=42, weight_seeds=(0, 1, 2, 3), nslab=32,
-                 process_group=None, checkpoint_root="./checkpoints"):
+                 process_group=None, checkpoint_root="./checkpoints", two_streams=True):
         if dimsize < 74:
             raise RuntimeError("minimum dimension allowed is 74")            # cgan.py:52-53
         H.require_gpu()
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
         self.dimsize, self.exp_name, self.is3d = dimsize, exp_name, is3d
         self.focal_gamma, self.nslab = focal_gamma, nslab
+        self.two_streams = two_streams
         self.pg = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if self._dist() else 1
         self.rank = torch.distributed.get_rank(process_group) if self._dist() else 0
@@ -256,10 +276,59 @@ class EM2EM(object):
         st.real_y.copy_(real_y, non_blocking=True)
         return self._run_step(st)
 
+    def _run_two_streams(self, st):
+        cur = torch.cuda.current_stream()
+        st.events["inputs"].record(cur)              # losses cleared + inputs copied
+        # Host-side enqueue order: a list runs until it needs an event the other list has not recorded yet,
+        # then the other list is pumped ("adv" and "side_done" come from the side list, "fake_*" from main).
+        it_main, it_side = iter(st.main), iter(st.side)
+        recorded = {"inputs"}
+
+        def pump(it, stream):
+            """Enqueue items until the list ends or it needs an event nobody has recorded yet."""
+            raw = stream.cuda_stream
+            for item in it:
+                if isinstance(item, tuple):
+                    kind, name = item
+                    if kind == "record":
+                        st.events[name].record(stream); recorded.add(name)
+                    elif name in recorded:
+                        stream.wait_event(st.events[name])
+                    else:
+                        return item                   # blocked: hand back the pending wait
+                else:
+                    item(raw)
+            return None
+
+        pend_m = pend_s = None
+        done_m = done_s = False
+        while not (done_m and done_s):
+            progressed = False
+            for which in ("main", "side"):
+                it, stream = (it_main, cur) if which == "main" else (it_side, st.side_stream)
+                pend = pend_m if which == "main" else pend_s
+                if (done_m if which == "main" else done_s):
+                    continue
+                if pend is not None:
+                    if pend[1] not in recorded:
+                        continue
+                    stream.wait_event(st.events[pend[1]])
+                    progressed = True
+                pend = pump(it, stream)
+                progressed = progressed or pend is None
+                if which == "main":
+                    pend_m, done_m = pend, pend is None
+                else:
+                    pend_s, done_s = pend, pend is None
+            assert progressed or (done_m and done_s), "two-stream schedule deadlocked"
+
     def _run_step(self, st):
         s = H.current_stream()
         st.losses.zero_()
-        H.run(st.compute, s)
+        if self.two_streams:
+            self._run_two_streams(st)
+        else:
+            H.run(st.compute, s)
         if self.world_size > 1:
             D.allreduce_sum_(self.grad_all, self.pg)     # RCCL over xGMI (sum; the Adam kernel scales by 1/world)
         H.run(st.update, s)

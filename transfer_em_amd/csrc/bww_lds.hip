@@ -18,6 +18,7 @@
 // [16 co] -- the channels-last layout as it is.
 #include "tem_common.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace bwwlds {
 
@@ -399,17 +400,17 @@ int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
   if (!aligned(i0) || (a->in1.ptr && !aligned(a->in1)) || !aligned(g)) return TEM_EUNSUPPORTED;
   //        CI  CO  K  S  waves  X-chunks  G-chunks     (tiles per wave = ceil(K^3*CI/16 * ceil(CO/16) / waves))
   BWW_CASE(1, 8, 3, 1, 4, 6, 8)      // g.c0 / d.d1a: 2 tiles, HBM-bound on the gradient stream
-  BWW_CASE(8, 8, 3, 1, 4, 8, 5)      // g.d1a: 14 tiles
-  BWW_CASE(8, 16, 3, 1, 4, 8, 5)     // g.d2a / d.hack
-  BWW_CASE(16, 16, 3, 1, 4, 8, 5)    // g.f1: 27 tiles, 7 per wave
-  BWW_CASE(16, 32, 3, 1, 4, 8, 5)    // g.u2a / d.d2a: 54 tiles
+  BWW_CASE(8, 8, 3, 1, 8, 4, 3)      // g.d1a: 14 tiles
+  BWW_CASE(8, 16, 3, 1, 8, 4, 3)     // g.d2a / d.hack
+  BWW_CASE(16, 16, 3, 1, 8, 4, 3)    // g.f1: 27 tiles, 4 per wave (two waves per SIMD hide LDS latency)
+  BWW_CASE(16, 32, 3, 1, 8, 4, 3)    // g.u2a / d.d2a: 54 tiles
   BWW_CASE(32, 32, 3, 1, 8, 5, 3)    // g.mid / d.d3a: 108 tiles, 14 per wave
   BWW_CASE(32, 16, 3, 1, 8, 5, 3)    // g.u1a: 54 tiles
   BWW_CASE(16, 1, 3, 1, 4, 8, 5)     // (kept for callers that do not use the swapped C_out = 1 form)
   BWW_CASE(1, 16, 3, 1, 4, 6, 8)     // g.f2 swapped: X := dy (1 ch), G := f1 (16 ch), pad 2 -> dW with flipped taps
-  BWW_CASE(8, 8, 4, 2, 4, 12, 3)     // g.d1b / d.d1b: 32 tiles
+  BWW_CASE(8, 8, 4, 2, 8, 6, 2)      // g.d1b / d.d1b: 32 tiles
   BWW_CASE(16, 16, 4, 2, 8, 6, 3)    // g.d2b: 64 tiles
-  BWW_CASE(8, 16, 4, 2, 4, 12, 4)    // g.u1b (transposed conv: roles of input and gradient swapped)
+  BWW_CASE(8, 16, 4, 2, 8, 6, 2)     // g.u1b (transposed conv: roles of input and gradient swapped)
   BWW_CASE(16, 32, 4, 2, 4, 12, 4)   // g.u2b: 128 tiles, 32 per wave (1 wave per SIMD: 512 registers)
   // (32,32,k4,s2) -- the discriminator's two deep stride-2 layers, 1 GFLOP together -- would need 256
   // accumulator tiles per workgroup; they stay on the global-load kernel in conv_bww.hip.

@@ -66,6 +66,8 @@ struct Dev {
 template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MTW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   constexpr int CIP = CI + 2, NT = (CO + 15) / 16, KS = CI / 4, NTHR = NW * 64, NTAP = K * K * K;
+  constexpr int TAIL = S == 1 ? 20 : 40;                  // voxels the last tiles over-read past the ring
+  constexpr int TPITCH = 20;                              // floats per row of the epilogue transpose tile
   static_assert(CI % 8 == 0 && NW % NT == 0, "");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rowpitch = p.WP * CIP;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   const int nsteps = oz1 - oz0;
 
   {  // zero the LDS image once: pad voxels and the tail the last tiles over-read stay finite
-    const int total4 = (K * slotpitch + 40 * CIP + 3) / 4;
+    const int total4 = (K * slotpitch + TAIL * CIP + 3) / 4;
     for (int i = tid; i < total4; i += NTHR) reinterpret_cast<float4 *>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
@@ -168,59 +170,79 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
     return lds + (slot * slotpitch + (dy * p.WP + dx) * CIP);
   };
 
-  // ---- epilogue: lane holds co = nt*16 + m for voxels 4*kq + q of each tile (C/D map)
+  // ---- epilogue.  The MFMA leaves each lane with ONE channel of FOUR voxels (C/D map: col = lane&15,
+  // row = 4*(lane>>4)+reg).  Every wave transposes its 16x16 tile through a private 1.25 KB LDS patch
+  // so that a lane owns FOUR consecutive channels of ONE voxel: the gate / add loads and the stores
+  // become single 16-byte accesses (a full 64-byte channel run per voxel, 1 KB per wave-instruction),
+  // and the dropout bits of the four channels come from one Philox call.
+  float *tp = lds + ((K * slotpitch + TAIL * CIP + 3) & ~3) + wave * (16 * TPITCH);   // 16-byte aligned
+  const int ti = lane >> 2, tcq = lane & 3;               // transposed role: voxel row, channel quad
+  const int tco = nt * 16 + tcq * 4;
   auto epilogue = [&](const f32x4 (&acc)[MTW], int oz) {
-    if (bvalid) {
-      const bool first = co < p.CO0;
-      float *optr = first ? p.out0 + (n * p.o0N + oz * p.o0D + co) : p.out1 + (n * p.o1N + oz * p.o1D + (co - p.CO0));
-      const int oH = first ? p.o0H : p.o1H, oW = first ? p.o0W : p.o1W;
-      const Ep32 &ep = p.ep;
-      const float *gptr = ep.gate ? ep.gate + (n * ep.gN + oz * ep.gD + co) : nullptr;
-      const int az = oz - ep.aoz;
-      const float *aptr = (ep.add && (unsigned)az < (unsigned)ep.aDd) ? ep.add + (n * ep.aN + az * ep.aD + co) : nullptr;
-      const float bias = (ep.bias && first) ? ep.bias[co] : 0.f;
-      DropoutStream ds = ep.ds;
-      if (ep.dropout && ep.step_dev) ds.step = *ep.step_dev;
+    const bool first = tco < p.CO0;
+    const bool cvalid = tco < CO;
+    float *optr = first ? p.out0 + (n * p.o0N + oz * p.o0D + tco) : p.out1 + (n * p.o1N + oz * p.o1D + (tco - p.CO0));
+    const int oH = first ? p.o0H : p.o1H, oW = first ? p.o0W : p.o1W;
+    const Ep32 &ep = p.ep;
+    const float *gptr = ep.gate ? ep.gate + (n * ep.gN + oz * ep.gD + tco) : nullptr;
+    const int az = oz - ep.aoz;
+    const float *aptr = (ep.add && (unsigned)az < (unsigned)ep.aDd) ? ep.add + (n * ep.aN + az * ep.aD + tco) : nullptr;
+    DropoutStream ds = ep.ds;
+    if (DROP && ep.dropout && ep.step_dev) ds.step = *ep.step_dev;
 #pragma unroll
-      for (int j = 0; j < MTW; ++j) {
-        const int pr = wave + j * NW;
-        if (pr < npairs) {
-          int t = pr / NT;
-          asm volatile("" : "+s"(t));                      // per-step recompute: no hoisted per-tile registers
-          int r, ox;
-          if (S == 1) {
-            const int v = t * 16 + kq * 4;
-            r = __umulhi((uint32_t)v, p.magicWP);
-            ox = v - r * p.WP;
-          } else {
-            r = p.nseg == 1 ? t : (int)__umulhi((uint32_t)t, p.magicSeg);   // magic for d == 1 overflows 32 bits
-            ox = (t - r * p.nseg) * 16 + kq * 4;
-          }
-          uint64_t pblk = ~0ull;
-          Philox128 ph{};
+    for (int j = 0; j < MTW; ++j) {
+      const int pr = wave + j * NW;
+      if (pr < npairs) {                                   // wave-uniform
+        int t = pr / NT;
+        asm volatile("" : "+s"(t));                        // per-step recompute: no hoisted per-tile registers
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int oy = oy0 + r;
-            if (r < p.R && oy < p.OH && ox < p.OW) {
-              float v = acc[j][q];
-              if (first) {
-                v += bias;
-                if (aptr) {
-                  const int ay = oy - ep.aoy, ax = ox - ep.aox;
-                  if ((unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw) v += aptr[ay * ep.aH + ax * ep.aW];
-                }
-                if (gptr) v = gptr[oy * ep.gH + ox * ep.gW] > 0.f ? v : ep.gate_slope * v;
-                if (DROP && ep.dropout) {
-                  const uint64_t e = ((((uint64_t)n * p.OD + oz) * p.OH + oy) * p.OW + ox) * (uint64_t)p.CO0 + co;
-                  if ((e >> 7) != pblk) { pblk = e >> 7; ph = ds.block(pblk); }
-                  v = DropoutStream::bit(ph, (uint32_t)(e & 127)) ? 2.f * v : 0.f;
-                }
-                if (ep.slope != 1.f) v = v > 0.f ? v : ep.slope * v;
-              }
-              if (!(p.dbg & 1)) optr[oy * oH + ox * oW] = v;
+        for (int q = 0; q < 4; ++q) tp[(kq * 4 + q) * TPITCH + m] = acc[j][q];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wave's own LDS writes have landed
+        const float4 v4 = *reinterpret_cast<const float4 *>(tp + ti * TPITCH + tcq * 4);
+        int r, ox;
+        if (S == 1) {
+          const int v = t * 16 + ti;
+          r = __umulhi((uint32_t)v, p.magicWP);
+          ox = v - r * p.WP;
+        } else {
+          r = p.nseg == 1 ? t : (int)__umulhi((uint32_t)t, p.magicSeg);   // magic for d == 1 overflows 32 bits
+          ox = (t - r * p.nseg) * 16 + ti;
+        }
+        const int oy = oy0 + r;
+        if (cvalid && r < p.R && oy < p.OH && ox < p.OW) {
+          float v[4] = {v4.x, v4.y, v4.z, v4.w};
+          if (first) {
+            if (ep.bias) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] += ep.bias[tco + c];
             }
-            if (S == 1) { if (++ox == p.WP) { ox = 0; ++r; } } else { ++ox; }
+            if (aptr) {
+              const int ay = oy - ep.aoy, ax = ox - ep.aox;
+              if ((unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(aptr + ay * ep.aH + ax * ep.aW);
+                v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+              }
+            }
+            if (gptr) {
+              const float4 g4 = *reinterpret_cast<const float4 *>(gptr + oy * ep.gH + ox * ep.gW);
+              v[0] = g4.x > 0.f ? v[0] : ep.gate_slope * v[0];
+              v[1] = g4.y > 0.f ? v[1] : ep.gate_slope * v[1];
+              v[2] = g4.z > 0.f ? v[2] : ep.gate_slope * v[2];
+              v[3] = g4.w > 0.f ? v[3] : ep.gate_slope * v[3];
+            }
+            if (DROP && ep.dropout) {
+              const uint64_t e = ((((uint64_t)n * p.OD + oz) * p.OH + oy) * p.OW + ox) * (uint64_t)p.CO0 + tco;
+              const Philox128 ph = ds.block(e >> 7);
+              const uint32_t eb = (uint32_t)(e & 127);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] = DropoutStream::bit(ph, eb + c) ? 2.f * v[c] : 0.f;
+            }
+            if (ep.slope != 1.f) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : ep.slope * v[c];
+            }
           }
+          if (!(p.dbg & 1)) *reinterpret_cast<float4 *>(optr + oy * oH + ox * oW) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
@@ -310,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
 }
 
 // ------------------------------------------------------------------------------------------ host
-constexpr int LDS_BUDGET = 158 * 1024;
+constexpr int LDS_MAX = 160 * 1024;                     // gfx950: 160 KiB per workgroup
 static thread_local char *g_name = nullptr;   // set by tem_conv_describe around a dry run
 static thread_local int g_name_len = 0;
 constexpr int TARGET_BLOCKS = 512;
@@ -346,8 +368,9 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
   for (int r = 1; r <= (p.OH < 16 ? p.OH : 16); ++r) {
     int YR = (r - 1) * S + K;
     int ntiles = S == 1 ? (r * p.WP + 15) / 16 : r * p.nseg;
-    size_t bytes = ((size_t)K * YR * p.WP * CIP + 40 * CIP) * 4;   // + tail the last tiles over-read
-    bool fits = bytes <= (size_t)LDS_BUDGET && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * NTHR &&
+    // ring + tail the last tiles over-read + one 16 x 20 transpose patch per wave
+    size_t bytes = ((size_t)K * YR * p.WP * CIP + (S == 1 ? 20 : 40) * CIP + 4 + NW * 16 * 20) * 4;
+    bool fits = bytes <= (size_t)LDS_MAX && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * NTHR &&
                 ntiles * NT <= MTW * NW;
     if (!fits) continue;
     int rounds = (ntiles * NT + NW - 1) / NW;                      // tile slots each wave executes per step
@@ -471,6 +494,10 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
     return ((uintptr_t)v.ptr & 15) == 0 && v.sW % 4 == 0 && v.sH % 4 == 0 && v.sD % 4 == 0 && v.sN % 4 == 0;
   };
   if (!aligned(i0) || (a->in1.ptr && !aligned(a->in1))) return TEM_EUNSUPPORTED;
+  // the epilogue moves 4 channels per lane as one 16-byte access
+  if (!aligned(o0) || o0.C % 4 || (a->out1.ptr && (!aligned(a->out1) || a->out1.C % 4))) return TEM_EUNSUPPORTED;
+  if (e.gate.ptr && !aligned(e.gate)) return TEM_EUNSUPPORTED;
+  if (e.add.ptr && !aligned(e.add)) return TEM_EUNSUPPORTED;
   const int K = a->kd, S = a->sd;
   //         CI  CO  K  S  waves  X-chunks  tiles/wave
   // (8,8,k3) and (16,8,k3): C_out = 8 fills half of a 16-wide MFMA tile; the direct VALU kernel is
@@ -480,10 +507,10 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   CONV_CASE(16, 32, 3, 1, 8, 6, 4)     // g.u2a, d.d2a fwd; input-gradient of g.u1a
   CONV_CASE(32, 16, 3, 1, 8, 6, 4)     // g.u1a fwd; input-gradients of the 16->32 layers
   CONV_CASE(32, 32, 3, 1, 8, 6, 4)     // g.mid fwd (concat 16+16) and input-gradient (split 16|16); d.d3a
-  CONV_CASE(8, 8, 4, 2, 8, 7, 4)       // g.d1b, d.d1b fwd
+  // (8,8,k4,s2) and (8,16,k4,s2): 64 taps x 2 k-steps with half-empty N tiles -- the direct kernel is
+  // faster (46 vs 12 TFLOP/s measured on g.d1b); left to conv_direct.hip.
   CONV_CASE(16, 16, 4, 2, 8, 7, 4)     // g.d2b fwd
   CONV_CASE(32, 32, 4, 2, 8, 7, 4)     // d.d2b, d.d3b fwd
-  CONV_CASE(8, 16, 4, 2, 8, 7, 4)      // input-gradient of the transposed conv g.u1b (k4 s2 p1)
   CONV_CASE(16, 32, 4, 2, 8, 7, 4)     // input-gradient of g.u2b
   CONV_CASE_DROP(16, 16, 3, 1, 8, 6, 4)  // input-gradient of g.f1 through Dropout (split 8|8)
   CONV_CASE_DROP(32, 32, 3, 1, 8, 6, 4)  // input-gradient of g.mid through Dropout (split 16|16)
