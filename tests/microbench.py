@@ -8,6 +8,10 @@ from transfer_em_amd import hip_ops as H
 
 H.require_gpu()
 dev = "cuda"
+STAMPS = None
+if "--stamps" in sys.argv:       # diagnostic build path: per-phase cycle sums of conv_lds_k (see conv_lds.hip STAMP)
+    STAMPS = torch.zeros(600 * 8 * 8, dtype=torch.int64, device=dev)
+    os.environ["TEM_STAMP_BUF"] = hex(STAMPS.data_ptr())
 rnd = lambda *s: torch.randn(*s, device=dev, dtype=torch.float32)
 # name: (CI, CO, k, s, in_edge)
 GEOM = dict(f1=(16, 16, 3, 1, 100), mid=(32, 32, 3, 1, 54), d1a=(8, 8, 3, 1, 130), u1a=(32, 16, 3, 1, 52),
@@ -60,5 +64,13 @@ for name in args or ["f1"]:
         l(s)
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / iters
+    if STAMPS is not None:
+        t = STAMPS.cpu().numpy().reshape(-1, 8, 8).astype(float)
+        t = t[t.sum(axis=(1, 2)) > 0]
+        names = ["zero+prologue", "load_x issue", "late epilogue", "MFMA", "early epi/copy", "barrier1", "store_x", "barrier2"]
+        for half, sl in (("early waves", slice(0, 4)), ("late waves", slice(4, 8))):
+            m = t[:, sl, :].mean(axis=(0, 1))
+            print(f"  {half}: " + "  ".join(f"{n}={v/1e3:.1f}k" for n, v in zip(names, m)) + f"  total={m.sum()/1e3:.1f}k cyc/block")
+        STAMPS.zero_()
     print(f"{name:10s} {l.meta['kernel']:36s} {us:9.1f} us  {l.meta['flops'] / us / 1e6:7.2f} TFLOP/s  "
           f"{l.meta['bytes'] / us / 1e3:8.1f} GB/s")

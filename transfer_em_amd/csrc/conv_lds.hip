@@ -59,6 +59,7 @@ struct Dev {
   int32_t ntiles, nseg;          // m-tiles per z-step; x-segments per row (S == 2 only)
   uint32_t magicX, magicWP, magicSeg;
   int32_t chunksX;
+  unsigned long long *stamps;    // diagnostic: per-phase cycle sums [block][wave][8] (null in normal runs)
   int32_t dbg;                   // ablation switches (TEM_DEBUG_FLAGS env, perf triage only): 1 no stores, 2 no MFMA, 4 no prefetch
   Ep32 ep;
 };
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   constexpr int CIP = CI + 2, NT = (CO + 15) / 16, KS = CI / 4, NTHR = NW * 64, NTAP = K * K * K;
   constexpr int TAIL = S == 1 ? 20 : 40;                  // voxels the last tiles over-read past the ring
   constexpr int TPITCH = 20;                              // floats per row of the epilogue transpose tile
-  static_assert(CI % 8 == 0 && NW % NT == 0, "");
+  static_assert(CI % 16 == 0 && NW % NT == 0, "C_in 16 or 32: an even number of k-step pairs per tap");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rowpitch = p.WP * CIP;
   const int slotpitch = p.YR * rowpitch;
@@ -86,20 +87,22 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   const int oz1 = min(p.OD, oz0 + p.zper);
   const int nsteps = oz1 - oz0;
 
-  {  // zero the LDS image once: pad voxels and the tail the last tiles over-read stay finite
-    const int total4 = (K * slotpitch + TAIL * CIP + 3) / 4;
-    for (int i = tid; i < total4; i += NTHR) reinterpret_cast<float4 *>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned long long t_last = p.stamps ? clock64() : 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) do { if (p.stamps) { unsigned long long t_now = clock64(); t_sum[i] += t_now - t_last; t_last = t_now; } } while (0)
+  {  // the loader rewrites every ring voxel (out-of-range ones as zeros); only the tail the last tiles
+     // over-read must be cleared once so that it stays finite
+    float *tail = lds + K * slotpitch;
+    for (int i = tid; i < TAIL * CIP; i += NTHR) tail[i] = 0.f;
   }
-  __syncthreads();
 
   // ---- loader of S new input planes per step (register staged)
   const int in0_n = n * p.i0N, in1_n = n * p.i1N;
   const int iy_base = oy0 * S - p.P;
-  auto load_x = [&](float4 (&pf)[MAXPFX], int iz_first, int nplanes) {
+  auto load_x = [&](float4 (&pf)[MAXPFX], int iz_first, int nplanes, int ltid, int lthreads) {
     const int total = nplanes * p.YR * p.chunksX;
 #pragma unroll
     for (int i = 0; i < MAXPFX; ++i) {
-      int id = tid + i * NTHR;
+      int id = ltid + i * lthreads;
       asm volatile("" : "+v"(id));                         // recompute per step: keeps index math out of live registers
       bool ok = id < total;
       int rowid = __umulhi((uint32_t)id, p.magicX);
@@ -115,12 +118,12 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
       pf[i] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto store_x = [&](const float4 (&pf)[MAXPFX], int iz_first, int nplanes) {
+  auto store_x = [&](const float4 (&pf)[MAXPFX], int iz_first, int nplanes, int ltid, int lthreads) {
     const int total = nplanes * p.YR * p.chunksX;
     const int slot0 = ((iz_first % K) + K) % K, slot1 = (slot0 + 1) % K;
 #pragma unroll
     for (int i = 0; i < MAXPFX; ++i) {
-      int id = tid + i * NTHR;
+      int id = ltid + i * lthreads;
       asm volatile("" : "+v"(id));
       if (id < total) {
         int rowid = __umulhi((uint32_t)id, p.magicX);
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   // ---- this wave's output tiles: pair index = mtile*NT + nt, dealt round-robin (nt fixed per wave)
   const int nt = wave % NT;
   const int npairs = p.ntiles * NT;
-  int abase[MTW];                                        // LDS float index of this lane's A voxel, tap (0,0,0), ci = kq
+  int abase[MTW];                                        // LDS float index of this lane's A voxel, tap (0,0,0)
 #pragma unroll
   for (int j = 0; j < MTW; ++j) {
     int pr = min(wave + j * NW, npairs - 1);             // surplus tiles recompute the last one, never stored
@@ -151,18 +154,22 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
       int r = p.nseg == 1 ? t : (int)__umulhi((uint32_t)t, p.magicSeg), x0 = (t - r * p.nseg) * 16;
       vox = r * S * p.WP + (x0 + m) * S;
     }
-    abase[j] = vox * CIP + kq;
+    abase[j] = vox * CIP + 2 * kq;                         // this lane's channel pair of k-step pair 0
   }
-  // ---- kernel-tap fragment address (lane: ci = 4*s + kq, co = nt*16 + (lane&15))
+  // ---- kernel-tap fragments.  MFMA k-step u = 2p + w of a tap multiplies channels ci = 8p + 2*kq + w
+  // (kq = lane>>4): a lane's two channels of a k-step PAIR are adjacent, so its A fragment for both
+  // k-steps is ONE ds_read_b64 -- half the LDS instructions and two k-steps of MFMA work (8 MFMAs at
+  // MTW 4) per LDS round trip.  The sum over ci is order-free, B just follows the same map.
   const int co = nt * 16 + m;
   const bool bvalid = co < CO;
   const int cob = bvalid ? co : 0;
-  const int bbase = p.flip ? cob * CI + kq : kq * CO + cob;
-  const int bstep = p.flip ? 4 : 4 * CO;                  // per k-step
   auto load_b = [&](float (&b)[KS], int tap) {
-    const float *wt = p.w + ((p.flip ? NTAP - 1 - tap : tap) * (CI * CO) + bbase);
+    const float *wt = p.w + (p.flip ? NTAP - 1 - tap : tap) * (CI * CO);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) b[s] = bvalid ? wt[s * bstep] : 0.f;
+    for (int u = 0; u < KS; ++u) {
+      const int ci = 8 * (u / 2) + 2 * kq + (u & 1);
+      b[u] = bvalid ? wt[p.flip ? cob * CI + ci : ci * CO + cob] : 0.f;
+    }
   };
   auto tap_origin = [&](int tap, int izb) -> const float * {
     const int dz = tap / (K * K), rem = tap - dz * (K * K), dy = rem / K, dx = rem - dy * K;
@@ -254,13 +261,64 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
     constexpr int NB = (K + S - 1) / S;
     float4 pro[NB][MAXPFX];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) load_x(pro[b], iz0 + b * S, min(S, K - b * S));
+    for (int b = 0; b < NB; ++b) load_x(pro[b], iz0 + b * S, min(S, K - b * S), tid, NTHR);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) store_x(pro[b], iz0 + b * S, min(S, K - b * S));
+    for (int b = 0; b < NB; ++b) store_x(pro[b], iz0 + b * S, min(S, K - b * S), tid, NTHR);
   }
   __syncthreads();
 
+  STAMP(0);                                                // zero-fill + prologue
   const bool late = wave >= NW / 2;
+  // Steady-state loader (late half only): per-chunk descriptors are computed ONCE -- global offset inside a
+  // plane, LDS offset inside a slot, and three bit masks (chunk valid in y/x, second plane of a stride-2
+  // step, taken from in1) -- so that a step's loader is ~4 VALU per 16-byte chunk.
+  int goff[MAXPFX], loff[MAXPFX];
+  uint32_t okmask = 0, plmask = 0, srcmask = 0;
+  {
+    const int ltid = tid - NTHR / 2, total = S * p.YR * p.chunksX;
+#pragma unroll
+    for (int i = 0; i < MAXPFX; ++i) {
+      int id = ltid + i * (NTHR / 2);
+      bool ok = late && id < total;
+      int rowid = __umulhi((uint32_t)(ok ? id : 0), p.magicX);
+      int pos = (ok ? id : 0) - rowid * p.chunksX;
+      int pl = rowid >= p.YR ? 1 : 0;
+      int yr = rowid - pl * p.YR;
+      int vox = pos / (CI / 4);
+      int c = (pos - vox * (CI / 4)) * 4;
+      int iy = iy_base + yr, ix = vox - p.P;
+      bool inb = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      bool s1 = c >= p.C0;
+      goff[i] = s1 ? in1_n + iy * p.i1H + ix * p.i1W + (c - p.C0) : in0_n + iy * p.i0H + ix * p.i0W + c;
+      loff[i] = yr * rowpitch + vox * CIP + c;
+      okmask |= (inb ? 1u : 0u) << i;
+      plmask |= ((ok && pl) ? 1u : 0u) << i;
+      srcmask |= (s1 ? 1u : 0u) << i;
+      if (!ok) loff[i] = -1;                               // chunk does not exist for this thread
+    }
+  }
+  auto load_fast = [&](float4 (&pf)[MAXPFX], int iz_first) {
+#pragma unroll
+    for (int i = 0; i < MAXPFX; ++i) {
+      const int pl = (plmask >> i) & 1u;
+      const int iz = iz_first + pl;
+      const bool s1 = (srcmask >> i) & 1u;
+      const bool ok = ((okmask >> i) & 1u) && (unsigned)iz < (unsigned)p.D;
+      const float *src = (s1 ? p.in1 : p.in0) + (goff[i] + iz * (s1 ? p.i1D : p.i0D));
+      pf[i] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_fast = [&](const float4 (&pf)[MAXPFX], int iz_first) {
+    const int slot0 = ((iz_first % K) + K) % K, slot1 = (slot0 + 1) % K;
+#pragma unroll
+    for (int i = 0; i < MAXPFX; ++i) {
+      if (loff[i] >= 0) {
+        float *d = lds + ((((plmask >> i) & 1u) ? slot1 : slot0) * slotpitch + loff[i]);
+        *reinterpret_cast<float2 *>(d) = make_float2(pf[i].x, pf[i].y);
+        *reinterpret_cast<float2 *>(d + 2) = make_float2(pf[i].z, pf[i].w);
+      }
+    }
+  };
   f32x4 acc_prev[MTW];
 #pragma unroll
   for (int j = 0; j < MTW; ++j) acc_prev[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -269,9 +327,13 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
     const int oz = oz0 + step;
     const int izb = oz * S - p.P;
     const bool more = step + 1 < nsteps;
-    if (more && !(p.dbg & 4)) load_x(pfx, izb + K, S);    // next step's HBM/L2 reads fly during the MFMAs
+    // Only the late half fetches the next planes: the early half goes straight to its MFMA stream, so the
+    // matrix pipe is busy while the loader's address arithmetic and load issue run on the partner waves.
+    if (late && more && !(p.dbg & 4)) load_fast(pfx, izb + K);
 
+    STAMP(1);                                              // load_x issue
     if (late && step > 0) epilogue(acc_prev, oz - 1);
+    STAMP(2);                                              // early epilogue (late half)
 
     f32x4 acc[MTW];
 #pragma unroll
@@ -280,41 +342,38 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
     // Flat pipeline over (tap, k-step): the A fragments of the NEXT group are read from LDS before
     // the current group's MFMAs issue; B fragments of the next tap are fetched one tap ahead.
     float bcur[KS], bnxt[KS], bnx2[KS];                   // kernel taps: current, +1, +2 (two taps of latency cover)
-    float a0[MTW], a1[MTW];
+    constexpr int PP = KS / 2;                            // k-step pairs per tap (even: 2 or 4)
+    float2 A[2][MTW];
     load_b(bcur, 0);
     load_b(bnxt, NTAP > 1 ? 1 : 0);
     const float *xt = tap_origin(0, izb);
 #pragma unroll
-    for (int j = 0; j < MTW; ++j) a0[j] = xt[abase[j]];
+    for (int j = 0; j < MTW; ++j) A[0][j] = *reinterpret_cast<const float2 *>(xt + abase[j]);
     for (int tap = 0; tap < ((p.dbg & 2) ? 1 : NTAP); ++tap) {
       const int tn = tap + 1 < NTAP ? tap + 1 : tap;
       const float *xn = tap_origin(tn, izb);
       load_b(bnx2, tap + 2 < NTAP ? tap + 2 : tap);
 #pragma unroll
-      for (int s = 0; s < KS; s += 2) {
+      for (int pp = 0; pp < PP; ++pp) {
+        constexpr int dummy = 0; (void)dummy;
+        const int cur = pp & 1, nxt = cur ^ 1;
+        // fragments of the NEXT pair (same tap, or pair 0 of the next tap) fly while this pair's MFMAs issue
 #pragma unroll
-        for (int j = 0; j < MTW; ++j) a1[j] = xt[abase[j] + (s + 1) * 4];
+        for (int j = 0; j < MTW; ++j)
+          A[nxt][j] = *reinterpret_cast<const float2 *>((pp + 1 < PP ? xt + 8 * (pp + 1) : xn) + abase[j]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < MTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bcur[s], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < KS) {
+        for (int j = 0; j < MTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][j].x, bcur[2 * pp], acc[j], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < MTW; ++j) a0[j] = xt[abase[j] + (s + 2) * 4];
-        } else {                                           // first group of the next tap
-#pragma unroll
-          for (int j = 0; j < MTW; ++j) a0[j] = xn[abase[j]];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < MTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bcur[s + 1], acc[j], 0, 0, 0);
+        for (int j = 0; j < MTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][j].y, bcur[2 * pp + 1], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int s = 0; s < KS; ++s) { bcur[s] = bnxt[s]; bnxt[s] = bnx2[s]; }
+      for (int u = 0; u < KS; ++u) { bcur[u] = bnxt[u]; bnxt[u] = bnx2[u]; }
       xt = xn;
     }
 
+    STAMP(3);                                              // MFMA phase
     // Waves NW/2.. share their SIMDs with waves 0..NW/2-1.  The upper half runs one step's epilogue
     // (pure VALU + stores) at the START of the next step, i.e. while its SIMD partner streams MFMAs,
     // and streams its own MFMAs while the partner runs its epilogue: matrix and vector pipes overlap.
@@ -324,11 +383,19 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
 #pragma unroll
       for (int j = 0; j < MTW; ++j) acc_prev[j] = acc[j];
     }
+    STAMP(4);                                              // epilogue (early half) / acc copy
     __syncthreads();                                       // all waves are done reading the oldest planes
-    if (more && !(p.dbg & 4)) store_x(pfx, izb + K, S);
+    STAMP(5);                                              // barrier 1 wait
+    if (late && more && !(p.dbg & 4)) store_fast(pfx, izb + K);
+    STAMP(6);                                              // store_x
     __syncthreads();
+    STAMP(7);                                              // barrier 2 wait
   }
   if (late && nsteps > 0) epilogue(acc_prev, oz1 - 1);
+  if (p.stamps && lane == 0) {
+    for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * NW + wave) * 8 + i] = t_sum[i];
+  }
+#undef STAMP
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -370,7 +437,7 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
     int ntiles = S == 1 ? (r * p.WP + 15) / 16 : r * p.nseg;
     // ring + tail the last tiles over-read + one 16 x 20 transpose patch per wave
     size_t bytes = ((size_t)K * YR * p.WP * CIP + (S == 1 ? 20 : 40) * CIP + 4 + NW * 16 * 20) * 4;
-    bool fits = bytes <= (size_t)LDS_MAX && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * NTHR &&
+    bool fits = bytes <= (size_t)LDS_MAX && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * (NTHR / 2) &&
                 ntiles * NT <= MTW * NW;
     if (!fits) continue;
     int rounds = (ntiles * NT + NW - 1) / NW;                      // tile slots each wave executes per step
@@ -469,6 +536,9 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
     static int dbg = -1;
     if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
     p.dbg = dbg;
+    static unsigned long long stamp_ptr = ~0ull;
+    if (stamp_ptr == ~0ull) { const char *v = getenv("TEM_STAMP_BUF"); stamp_ptr = v ? strtoull(v, nullptr, 16) : 0; }
+    p.stamps = (unsigned long long *)stamp_ptr;
   }
   const tem_epilogue &e = a->ep;
   Ep32 &q = p.ep;
@@ -502,18 +572,18 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   //         CI  CO  K  S  waves  X-chunks  tiles/wave
   // (8,8,k3) and (16,8,k3): C_out = 8 fills half of a 16-wide MFMA tile; the direct VALU kernel is
   // faster there (46 vs 27 TFLOP/s measured on g.d1a) -- they are left to conv_direct.hip.
-  CONV_CASE(8, 16, 3, 1, 8, 5, 8)      // g.d2a, d.hack fwd
-  CONV_CASE(16, 16, 3, 1, 8, 6, 4)     // g.f1 fwd (concat 8+8) and its input-gradient (split 8|8)
-  CONV_CASE(16, 32, 3, 1, 8, 6, 4)     // g.u2a, d.d2a fwd; input-gradient of g.u1a
-  CONV_CASE(32, 16, 3, 1, 8, 6, 4)     // g.u1a fwd; input-gradients of the 16->32 layers
-  CONV_CASE(32, 32, 3, 1, 8, 6, 4)     // g.mid fwd (concat 16+16) and input-gradient (split 16|16); d.d3a
+  // (8,16,k3): left to the direct kernel (same speed there, 30 TFLOP/s, and C_in = 8 has a single k-step pair)
+  CONV_CASE(16, 16, 3, 1, 8, 12, 4)     // g.f1 fwd (concat 8+8) and its input-gradient (split 8|8)
+  CONV_CASE(16, 32, 3, 1, 8, 12, 4)     // g.u2a, d.d2a fwd; input-gradient of g.u1a
+  CONV_CASE(32, 16, 3, 1, 8, 12, 4)     // g.u1a fwd; input-gradients of the 16->32 layers
+  CONV_CASE(32, 32, 3, 1, 8, 12, 4)     // g.mid fwd (concat 16+16) and input-gradient (split 16|16); d.d3a
   // (8,8,k4,s2) and (8,16,k4,s2): 64 taps x 2 k-steps with half-empty N tiles -- the direct kernel is
   // faster (46 vs 12 TFLOP/s measured on g.d1b); left to conv_direct.hip.
-  CONV_CASE(16, 16, 4, 2, 8, 7, 4)     // g.d2b fwd
-  CONV_CASE(32, 32, 4, 2, 8, 7, 4)     // d.d2b, d.d3b fwd
-  CONV_CASE(16, 32, 4, 2, 8, 7, 4)     // input-gradient of g.u2b
-  CONV_CASE_DROP(16, 16, 3, 1, 8, 6, 4)  // input-gradient of g.f1 through Dropout (split 8|8)
-  CONV_CASE_DROP(32, 32, 3, 1, 8, 6, 4)  // input-gradient of g.mid through Dropout (split 16|16)
+  CONV_CASE(16, 16, 4, 2, 8, 14, 4)     // g.d2b fwd
+  CONV_CASE(32, 32, 4, 2, 8, 14, 4)     // d.d2b, d.d3b fwd
+  CONV_CASE(16, 32, 4, 2, 8, 14, 4)     // input-gradient of g.u2b
+  CONV_CASE_DROP(16, 16, 3, 1, 8, 12, 4)  // input-gradient of g.f1 through Dropout (split 8|8)
+  CONV_CASE_DROP(32, 32, 3, 1, 8, 12, 4)  // input-gradient of g.mid through Dropout (split 16|16)
   return TEM_EUNSUPPORTED;
 }
 
