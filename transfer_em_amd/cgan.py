@@ -134,18 +134,25 @@ class _CompiledStep:
         #   side: D(real) | after fake_*: D(fake) -> adversarial + discriminator losses -> input-gradient of
         #         the adversarial term (joined into the generator sweep) -> discriminator sweep -> reduction
         L_ = lambda *plans: [l for pl in plans for l in pl.launches]
-        main, side = [], []
+        main, side, third = [], [], []
+        # side: discriminators
         side += [("wait", "inputs")] + L_(d_xr, d_yr)
-        main += L_(f_g1) + [("record", "fake_y")] + L_(f_f2, f_f1) + [("record", "fake_x")] + L_(f_g2, f_f3, f_g3)
         side += [("wait", "fake_y")] + L_(d_yf) + [("wait", "fake_x")] + L_(d_xf)
         side += [loss[0], loss[1]] + loss[6:10] + L_(a_dy, a_dx) + [("record", "adv")]
-        side += L_(w_dxr, w_dxf, w_dyr, w_dyf) + red["dx"] + red["dy"]
-        side += [("record", "side_done")]
-        main += loss[2:6] + L_(b_g3, b_f3, b_f2, b_g2) + [("wait", "adv"), add_y, add_x] + L_(b_g1, b_f1)
-        main += red["g"] + red["f"] + [("wait", "side_done")]
-        self.main, self.side = main, side
-        self.side_stream = torch.cuda.Stream(device=dev)
-        self.events = {k: torch.cuda.Event() for k in ("inputs", "fake_y", "fake_x", "adv", "side_done")}
+        side += L_(w_dxr, w_dxf, w_dyr, w_dyf) + red["dx"] + red["dy"] + [("record", "side_done")]
+        # main: generator G call sites; third: generator F call sites (their kernels overlap in the
+        # ramp-up / ramp-down of each other's grids)
+        main += L_(f_g1) + [("record", "fake_y")] + L_(f_g3) + [("wait", "fake_x")] + L_(f_g2)
+        third += [("wait", "inputs")] + L_(f_f1) + [("record", "fake_x")] + L_(f_f3) + [("wait", "fake_y")] + L_(f_f2)
+        main += [loss[3], loss[4]] + L_(b_g3, b_g2) + [("record", "d_fake_x")]
+        third += [loss[2], loss[5]] + L_(b_f3, b_f2) + [("record", "d_fake_y")]
+        main += [("wait", "adv"), ("wait", "d_fake_y"), add_y] + L_(b_g1) + red["g"]
+        third += [("wait", "adv"), ("wait", "d_fake_x"), add_x] + L_(b_f1) + red["f"] + [("record", "third_done")]
+        main += [("wait", "side_done"), ("wait", "third_done")]
+        self.lists = (main, side, third)
+        self.extra_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        self.events = {k: torch.cuda.Event() for k in ("inputs", "fake_y", "fake_x", "adv", "side_done", "d_fake_x",
+                                                       "d_fake_y", "third_done")}
 
         # ---- optimizer (cgan.py:218-228); gradients are averaged over ranks by grad_scale
         ws = m.world_size
@@ -276,57 +283,52 @@ class EM2EM(object):
         st.real_y.copy_(real_y, non_blocking=True)
         return self._run_step(st)
 
-    def _run_two_streams(self, st):
+    def _run_streams(self, st):
+        """Enqueue the step's launch lists on their streams.  Host-side order: a list runs until it needs an
+        event no list has recorded yet, then the others are pumped (events order the GPU side)."""
         cur = torch.cuda.current_stream()
         st.events["inputs"].record(cur)              # losses cleared + inputs copied
-        # Host-side enqueue order: a list runs until it needs an event the other list has not recorded yet,
-        # then the other list is pumped ("adv" and "side_done" come from the side list, "fake_*" from main).
-        it_main, it_side = iter(st.main), iter(st.side)
+        streams = (cur,) + st.extra_streams
+        its = [iter(l) for l in st.lists]
+        pending = [None] * len(its)
+        done = [False] * len(its)
         recorded = {"inputs"}
-
-        def pump(it, stream):
-            """Enqueue items until the list ends or it needs an event nobody has recorded yet."""
-            raw = stream.cuda_stream
-            for item in it:
-                if isinstance(item, tuple):
-                    kind, name = item
-                    if kind == "record":
-                        st.events[name].record(stream); recorded.add(name)
-                    elif name in recorded:
-                        stream.wait_event(st.events[name])
-                    else:
-                        return item                   # blocked: hand back the pending wait
-                else:
-                    item(raw)
-            return None
-
-        pend_m = pend_s = None
-        done_m = done_s = False
-        while not (done_m and done_s):
+        while not all(done):
             progressed = False
-            for which in ("main", "side"):
-                it, stream = (it_main, cur) if which == "main" else (it_side, st.side_stream)
-                pend = pend_m if which == "main" else pend_s
-                if (done_m if which == "main" else done_s):
+            for i, (it, stream) in enumerate(zip(its, streams)):
+                if done[i]:
                     continue
-                if pend is not None:
-                    if pend[1] not in recorded:
+                if pending[i] is not None:
+                    if pending[i] not in recorded:
                         continue
-                    stream.wait_event(st.events[pend[1]])
+                    stream.wait_event(st.events[pending[i]])
+                    pending[i] = None
                     progressed = True
-                pend = pump(it, stream)
-                progressed = progressed or pend is None
-                if which == "main":
-                    pend_m, done_m = pend, pend is None
-                else:
-                    pend_s, done_s = pend, pend is None
-            assert progressed or (done_m and done_s), "two-stream schedule deadlocked"
+                raw = stream.cuda_stream
+                blocked = False
+                for item in it:
+                    if isinstance(item, tuple):
+                        kind, name = item
+                        if kind == "record":
+                            st.events[name].record(stream); recorded.add(name)
+                        elif name in recorded:
+                            stream.wait_event(st.events[name])
+                        else:
+                            pending[i] = name; blocked = True
+                            break
+                    else:
+                        item(raw)
+                    progressed = True
+                if not blocked:
+                    done[i] = True
+                    progressed = True
+            assert progressed, "stream schedule deadlocked"
 
     def _run_step(self, st):
         s = H.current_stream()
         st.losses.zero_()
         if self.two_streams:
-            self._run_two_streams(st)
+            self._run_streams(st)
         else:
             H.run(st.compute, s)
         if self.world_size > 1:
