@@ -34,18 +34,29 @@ def synthetic_volume(shape, seed):
     return ((x - x.mean()) / x.std()).astype(np.float32)[..., None]
 
 
-def per_kernel_profile(model, st, steps):
-    """Time every launch of the step with HIP events on the launch stream; aggregate by kernel symbol."""
+def per_kernel_profile(model, st, steps, streams=True):
+    """Time every launch of the step with HIP events recorded on the stream the kernel is launched on,
+    aggregated by kernel symbol.  streams=True: the real multi-stream schedule (kernels of different
+    call sites overlap, as in the timed region and as rocprofv3 sees them); False: one stream, one
+    kernel at a time (stand-alone kernel quality)."""
     from transfer_em_amd import hip_ops as H
-    s = H.current_stream()
     agg = {}
     for _ in range(steps):
         st.losses.zero_()
         evs = []
-        for l in st.compute + st.update:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); l(s); b.record()
-            evs.append((l, a, b))
+        if streams and model.two_streams:
+            model._run_streams(st, trace=evs)
+            s = H.current_stream()
+            for l in st.update:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); l(s); b.record()
+                evs.append((l, a, b))
+        else:
+            s = H.current_stream()
+            for l in st.compute + st.update:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); l(s); b.record()
+                evs.append((l, a, b))
         torch.cuda.synchronize()
         for l, a, b in evs:
             k = l.meta.get("kernel", l.name.split(".")[0] + ".misc")
@@ -72,12 +83,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank % ndev)           # (rehearsals put several ranks on one card)
     dist = world > 1
     if dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("TEM_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            torch.distributed.init_process_group(backend)
 
     from transfer_em_amd.cgan import EM2EM
     n, B = args.dimsize, args.batch
@@ -109,7 +125,8 @@ def main():
     out = None
     if rank == 0:
         st = model._steps[B]
-        agg = per_kernel_profile(model, st, max(2, min(5, args.steps)))
+        agg = per_kernel_profile(model, st, max(2, min(5, args.steps)), streams=True)
+        alone = per_kernel_profile(model, st, 2, streams=False)
         dom_k, dom = max(((k, v) for k, v in agg.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         secs = dom["ms"] * 1e-3
         ai = dom["flops"] / dom["bytes"]
@@ -118,14 +135,29 @@ def main():
         else:
             roof = dict(bound="hbm", achieved=dom["bytes"] / secs / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # HBM bytes per launch of this kernel from the PMC passes (profiles/collect_traffic.py; the counters
+        # cannot be read inside this process) -- null when that kernel/shape has not been profiled
         roof["traffic"] = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            key = dom_k.split("(")[0]
+            if key in tr:
+                roof["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                roof["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["launches"]
+        except (OSError, ValueError):
+            pass
         roof["kernel"] = dom_k
         roof["avg_launch_us"] = dom["ms"] * 1e3 / dom["launches"]
         roof["share_of_step"] = dom["ms"] / sum(v["ms"] for v in agg.values())
+        if dom_k in alone and alone[dom_k]["ms"] > 0:      # same kernel with nothing else on the GPU
+            a1 = alone[dom_k]
+            roof["standalone_avg_launch_us"] = a1["ms"] * 1e3 / a1["launches"]
+            roof["standalone_frac"] = ((a1["flops"] / (a1["ms"] * 1e-3) / 1e12) / FP32_PEAK_TFLOPS if roof["bound"] == "mfma"
+                                       else (a1["bytes"] / (a1["ms"] * 1e-3) / 1e9) / HBM_PEAK_GBS)
         tot_flops = sum(v["flops"] for v in agg.values()) / max(2, min(5, args.steps))
         tot_bytes = sum(v["bytes"] for v in agg.values()) / max(2, min(5, args.steps))
         if args.kernel_table:
-            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            for k, v in sorted(alone.items(), key=lambda kv: -kv[1]["ms"]):
                 s_ = v["ms"] * 1e-3
                 print(f"{k:48s} {v['launches']:5d} launches {v['ms']:9.3f} ms  "
                       f"{v['flops'] / s_ / 1e12 if s_ else 0:7.2f} TFLOP/s {v['bytes'] / s_ / 1e9 if s_ else 0:8.1f} GB/s",

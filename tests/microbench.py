@@ -30,7 +30,9 @@ class _P:
 
 def build(name, direct=False):
     kind, layer = ("fwd", name)
-    if name.startswith("bd_"):
+    if name.startswith("bdd_"):          # input-gradient through Dropout with split outputs (g.bd.f1 / g.bd.mid)
+        kind, layer = "bdd", name[4:]
+    elif name.startswith("bd_"):
         kind, layer = "bd", name[3:]
     elif name.startswith("bww_"):
         kind, layer = "bww", name[4:]
@@ -40,6 +42,12 @@ def build(name, direct=False):
     w = rnd(k ** 3 * CI * CO) * 0.05
     if kind == "fwd":
         return H.conv_launch(name, x, w, y, k, s, 0, slope=0.3, direct=direct)
+    if kind == "bdd":
+        half = CI // 2
+        o0, o1 = rnd(1, n, n, n, half), rnd(1, n, n, n, half)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        return H.conv_launch(name, y, w, o0, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI, out1=o1, gate=torch.randn_like(o0),
+                             dropout=(42, 1, step), direct=direct)
     if kind == "bd":
         return H.conv_launch(name, y, w, x, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI, gate=torch.randn_like(x), direct=direct)
     ws = H.GradWorkspace(_P((k, k, k, CI, CO)), 1)

@@ -283,8 +283,9 @@ class EM2EM(object):
         st.real_y.copy_(real_y, non_blocking=True)
         return self._run_step(st)
 
-    def _run_streams(self, st):
-        """Enqueue the step's launch lists on their streams.  Host-side order: a list runs until it needs an
+    def _run_streams(self, st, trace=None):
+        """Enqueue the step's launch lists on their streams.  `trace` (bench.py): list receiving
+        (launch, start_event, end_event) with the events recorded on the launch's own stream.  Host-side order: a list runs until it needs an
         event no list has recorded yet, then the others are pumped (events order the GPU side)."""
         cur = torch.cuda.current_stream()
         st.events["inputs"].record(cur)              # losses cleared + inputs copied
@@ -316,8 +317,12 @@ class EM2EM(object):
                         else:
                             pending[i] = name; blocked = True
                             break
-                    else:
+                    elif trace is None:
                         item(raw)
+                    else:
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record(stream); item(raw); b.record(stream)
+                        trace.append((item, a, b))
                     progressed = True
                 if not blocked:
                     done[i] = True
