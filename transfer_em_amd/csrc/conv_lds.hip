@@ -341,36 +341,46 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
 
     // Flat pipeline over (tap, k-step): the A fragments of the NEXT group are read from LDS before
     // the current group's MFMAs issue; B fragments of the next tap are fetched one tap ahead.
-    float bcur[KS], bnxt[KS], bnx2[KS];                   // kernel taps: current, +1, +2 (two taps of latency cover)
+    // Kernel taps live in a ring of three register sets: tap t multiplies with set t%3 while the loads
+    // of tap t+2 fill set (t+2)%3 -- two whole taps (>= 1000 cycles) of L2 latency cover and no
+    // register-to-register rotation (a copy would force the wait one tap early).  The tap loop is
+    // unrolled by 3 so that the set indices are static.
     constexpr int PP = KS / 2;                            // k-step pairs per tap (even: 2 or 4)
+    const int ntap_run = ((p.dbg & 2) || ((p.dbg & 64) && late) || ((p.dbg & 128) && !late)) ? 1 : NTAP;   // ablations
+    float B[3][KS];
     float2 A[2][MTW];
-    load_b(bcur, 0);
-    load_b(bnxt, NTAP > 1 ? 1 : 0);
+    load_b(B[0], 0);
+    load_b(B[1], NTAP > 1 ? 1 : 0);
     const float *xt = tap_origin(0, izb);
 #pragma unroll
     for (int j = 0; j < MTW; ++j) A[0][j] = *reinterpret_cast<const float2 *>(xt + abase[j]);
-    for (int tap = 0; tap < ((p.dbg & 2) ? 1 : NTAP); ++tap) {
-      const int tn = tap + 1 < NTAP ? tap + 1 : tap;
-      const float *xn = tap_origin(tn, izb);
-      load_b(bnx2, tap + 2 < NTAP ? tap + 2 : tap);
+    for (int tap0 = 0; tap0 < ntap_run; tap0 += 3) {
 #pragma unroll
-      for (int pp = 0; pp < PP; ++pp) {
-        constexpr int dummy = 0; (void)dummy;
-        const int cur = pp & 1, nxt = cur ^ 1;
-        // fragments of the NEXT pair (same tap, or pair 0 of the next tap) fly while this pair's MFMAs issue
+      for (int tb = 0; tb < 3; ++tb) {
+        const int tap = tap0 + tb;
+        if (tap < ntap_run) {                              // wave-uniform
+          const int tn = tap + 1 < NTAP ? tap + 1 : tap;
+          const float *xn = tap_origin(tn, izb);
+          load_b(B[(tb + 2) % 3], tap + 2 < NTAP ? tap + 2 : tap);
 #pragma unroll
-        for (int j = 0; j < MTW; ++j)
-          A[nxt][j] = *reinterpret_cast<const float2 *>((pp + 1 < PP ? xt + 8 * (pp + 1) : xn) + abase[j]);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int pp = 0; pp < PP; ++pp) {
+            const int cur = pp & 1, nxt = cur ^ 1;
+            // fragments of the NEXT pair (same tap, or pair 0 of the next tap) fly while this pair's MFMAs issue
 #pragma unroll
-        for (int j = 0; j < MTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][j].x, bcur[2 * pp], acc[j], 0, 0, 0);
+            for (int j = 0; j < MTW; ++j)
+              A[nxt][j] = *reinterpret_cast<const float2 *>((pp + 1 < PP ? xt + 8 * (pp + 1) : xn) + abase[j]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < MTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][j].y, bcur[2 * pp + 1], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < MTW; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][j].x, B[tb][2 * pp], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < MTW; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][j].y, B[tb][2 * pp + 1], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          xt = xn;
+        }
       }
-#pragma unroll
-      for (int u = 0; u < KS; ++u) { bcur[u] = bnxt[u]; bnxt[u] = bnx2[u]; }
-      xt = xn;
     }
 
     STAMP(3);                                              // MFMA phase
@@ -445,7 +455,7 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
     int cols = p.N * nych;
     if (rounds > MTW) continue;
     double step = 2.0 * MTW * NTAPS * KSTEPS * 32.0 * 1.35 + 2500.0 + 600.0 * MTW;   // every wave runs MTW slots
-    double pro = 9000.0 + bytes / 64.0;
+    double pro = 12000.0 + bytes / 12.0;              // first K planes arrive at the CU's HBM share (~12 B/clk)
     for (int zs = 1; zs <= p.OD; ++zs) {
       int zper = (p.OD + zs - 1) / zs, zsegs = (p.OD + zper - 1) / zper;
       if (zsegs != zs) continue;
