@@ -51,7 +51,8 @@ typedef struct tem_view {
  *                                              gated on the saved forward output)
  *     v = keep(element) ? 2 v : 0             (if dropout: Philox4x32-10 stream
  *                                              (seed, site, step); element = dense
- *                                              NDHWC index in out0)
+ *                                              NDHWC index in out0, or in the
+ *                                              full tensor out0 is a window of)
  *     v = v > 0 ? v : slope * v               (forward LeakyReLU; slope 1 = linear)
  *
  * Channels written to out1 (the second half of a split output) skip add/gate/
@@ -75,6 +76,12 @@ typedef struct tem_epilogue {
   uint32_t     step;
   const uint32_t *step_dev;   /* if non-NULL the step is read from device memory
                                  (graph replay) and `step` is ignored               */
+  /* When out0 is a window of a larger logical tensor (region-restricted execution of the cycle
+   * path), the dropout element index is taken in the frame of that full tensor: voxel
+   * (z,y,x) of out0 is voxel (z,y,x) + drop_org of a tensor with spatial extents drop_dims.
+   * drop_dims[0] == 0: out0 itself is the full tensor. */
+  int32_t      drop_org[3];
+  int32_t      drop_dims[3];
 } tem_epilogue;
 
 /* Weight addressing for tem_conv: element (tap, c_in, c_out) of the operator's

@@ -60,9 +60,10 @@ class _CompiledStep:
 
         # ---- forward (cgan.py:152-189)
         f_g1 = GenForward(G, self.real_x, training=True, drop=drop(CALL_G_FAKE_Y), **kw)
-        f_f2 = GenForward(F, f_g1.y, in_pad=b, training=True, drop=drop(CALL_F_CYC_X), **kw)
+        # cycle path: only the window of `cycled` that survives the crop (cgan.py:163,172) is evaluated
+        f_f2 = GenForward(F, f_g1.y, in_pad=b, training=True, drop=drop(CALL_F_CYC_X), out_crop=b, **kw)
         f_f1 = GenForward(F, self.real_y, training=True, drop=drop(CALL_F_FAKE_X), **kw)
-        f_g2 = GenForward(G, f_f1.y, in_pad=b, training=True, drop=drop(CALL_G_CYC_Y), **kw)
+        f_g2 = GenForward(G, f_f1.y, in_pad=b, training=True, drop=drop(CALL_G_CYC_Y), out_crop=b, **kw)
         f_f3 = GenForward(F, self.real_x, training=True, drop=drop(CALL_F_SAME_X), **kw)
         f_g3 = GenForward(G, self.real_y, training=True, drop=drop(CALL_G_SAME_Y), **kw)
         x_c, y_c = cr(self.real_x, b), cr(self.real_y, b)
@@ -79,16 +80,16 @@ class _CompiledStep:
         z = lambda t: torch.zeros_like(t)
         dz_gen_g, dz_gen_f = z(d_yf.z), z(d_xf.z)
         dz_rx, dz_fx, dz_ry, dz_fy = z(d_xr.z), z(d_xf.z), z(d_yr.z), z(d_yf.z)
-        dcyc_x, dcyc_y = z(f_f2.y), z(f_g2.y)          # zero outside the cropped window, forever
+        dcyc_x, dcyc_y = z(f_f2.y), z(f_g2.y)          # gradients w.r.t. the evaluated (cropped) windows
         dsame_x, dsame_y = z(f_f3.y), z(f_g3.y)
         Ls = self.losses
         loss = [
             H.focal_logits_launch("loss.gen_g", d_yf.z, 1, gamma, Ls, _bits(L_TOTAL_G, L_GEN_G), 2.0, dz_gen_g, 2.0),
             H.focal_logits_launch("loss.gen_f", d_xf.z, 1, gamma, Ls, _bits(L_TOTAL_F, L_GEN_F), 2.0, dz_gen_f, 2.0),
-            H.focal_match_launch("loss.cyc_x", cr(self.real_x, 2 * b), cr(f_f2.y, b), gamma, Ls,
-                                 _bits(L_TOTAL_G, L_TOTAL_F, L_CYCLE), 4.0, cr(dcyc_x, b), 4.0),
-            H.focal_match_launch("loss.cyc_y", cr(self.real_y, 2 * b), cr(f_g2.y, b), gamma, Ls,
-                                 _bits(L_TOTAL_G, L_TOTAL_F, L_CYCLE), 4.0, cr(dcyc_y, b), 4.0),
+            H.focal_match_launch("loss.cyc_x", cr(self.real_x, 2 * b), f_f2.y, gamma, Ls,
+                                 _bits(L_TOTAL_G, L_TOTAL_F, L_CYCLE), 4.0, dcyc_x, 4.0),
+            H.focal_match_launch("loss.cyc_y", cr(self.real_y, 2 * b), f_g2.y, gamma, Ls,
+                                 _bits(L_TOTAL_G, L_TOTAL_F, L_CYCLE), 4.0, dcyc_y, 4.0),
             H.focal_match_launch("loss.id_y", y_c, f_g3.y, gamma, Ls, _bits(L_TOTAL_G), 2.0, dsame_y, 2.0),
             H.focal_match_launch("loss.id_x", x_c, f_f3.y, gamma, Ls, _bits(L_TOTAL_F), 2.0, dsame_x, 2.0),
             H.focal_logits_launch("loss.dx_real", d_xr.z, 1, gamma, Ls, _bits(L_DISC_X), 1.0, dz_rx, 1.0),

@@ -333,7 +333,9 @@ bool plan(Dev &p, int max_slabs, size_t &lds_bytes, int &nblocks) {
   if (R < 1) return false;
   p.nych = (p.OH + p.R - 1) / p.R;
   int cols = p.N * p.nych;
-  int want = max_slabs < TARGET_BLOCKS ? max_slabs : TARGET_BLOCKS;
+  static int target = -1;
+  if (target < 0) { const char *v = getenv("TEM_BWW_BLOCKS"); target = v ? atoi(v) : TARGET_BLOCKS; }
+  int want = max_slabs < target ? max_slabs : target;
   int zsegs = want / cols;
   if (zsegs < 1) zsegs = 1;
   if (zsegs > p.OD) zsegs = p.OD;

@@ -40,6 +40,7 @@ struct Ep32 {                    // epilogue with 32-bit strides
   int32_t dropout;
   DropoutStream ds;
   const uint32_t *step_dev;
+  int32_t doz, doy, dox, dD, dH, dW;
 };
 
 struct Dev {
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
               v[3] = g4.w > 0.f ? v[3] : ep.gate_slope * v[3];
             }
             if (DROP && ep.dropout) {
-              const uint64_t e = ((((uint64_t)n * p.OD + oz) * p.OH + oy) * p.OW + ox) * (uint64_t)p.CO0 + tco;
+              const uint64_t e = ((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) *
+                                     (uint64_t)p.CO0 + tco;
               const Philox128 ph = ds.block(e >> 7);
               const uint32_t eb = (uint32_t)(e & 127);
 #pragma unroll
@@ -570,6 +572,9 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   q.dropout = e.dropout;
   q.ds.k0 = (uint32_t)e.seed; q.ds.k1 = (uint32_t)(e.seed >> 32); q.ds.site = e.site; q.ds.step = e.step;
   q.step_dev = e.step_dev;
+  q.doz = e.drop_org[0]; q.doy = e.drop_org[1]; q.dox = e.drop_org[2];
+  q.dD = e.drop_dims[0] ? e.drop_dims[0] : o0.D; q.dH = e.drop_dims[0] ? e.drop_dims[1] : o0.H;
+  q.dW = e.drop_dims[0] ? e.drop_dims[2] : o0.W;
   auto aligned = [](const tem_view &v) {
     return ((uintptr_t)v.ptr & 15) == 0 && v.sW % 4 == 0 && v.sH % 4 == 0 && v.sD % 4 == 0 && v.sN % 4 == 0;
   };

@@ -55,6 +55,7 @@ struct EpilogueDev {
   int32_t dropout;
   DropoutStream ds;
   const uint32_t *step_dev;
+  int32_t doz, doy, dox, dD, dH, dW;     // dropout frame: origin of out0 inside the full tensor, full extents (dD == 0: none)
 };
 
 static inline EpilogueDev make_epilogue(const tem_epilogue &e) {
@@ -70,6 +71,8 @@ static inline EpilogueDev make_epilogue(const tem_epilogue &e) {
   d.ds.k0 = (uint32_t)e.seed; d.ds.k1 = (uint32_t)(e.seed >> 32);
   d.ds.site = e.site; d.ds.step = e.step;
   d.step_dev = e.step_dev;
+  d.doz = e.drop_org[0]; d.doy = e.drop_org[1]; d.dox = e.drop_org[2];
+  d.dD = e.drop_dims[0]; d.dH = e.drop_dims[1]; d.dW = e.drop_dims[2];
   return d;
 }
 
@@ -99,7 +102,8 @@ __device__ __forceinline__ void apply_epilogue(const EpilogueDev &ep, float (&v)
   if (ep.dropout) {
     DropoutStream ds = ep.ds;
     if (ep.step_dev) ds.step = *ep.step_dev;
-    uint64_t e = ((((uint64_t)n * D + z) * H + y) * W + x) * (uint64_t)C + c0;
+    uint64_t e = ep.dD ? ((((uint64_t)n * ep.dD + (z + ep.doz)) * ep.dH + (y + ep.doy)) * ep.dW + (x + ep.dox)) * (uint64_t)C + c0
+                       : ((((uint64_t)n * D + z) * H + y) * W + x) * (uint64_t)C + c0;
     Philox128 p = ds.block(e >> 7);
     uint32_t eb = (uint32_t)(e & 127);
 #pragma unroll

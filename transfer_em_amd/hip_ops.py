@@ -84,7 +84,7 @@ def _p3(p, is3d):
 
 def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=None, layout=TEM_W_TAP_CI_CO,
                 transposed=False, slope=1.0, bias=None, gate=None, gate_slope=LEAKY, add=None, add_off=0,
-                dropout=None, direct=False):
+                dropout=None, drop_frame=None, direct=False):
     """Build a tem_conv / tem_conv_transpose launch.  `w` and `bias` are 1-D float32 tensors
     (slices of a network's flat parameter vector); dropout = (seed, site, step_dev_tensor)."""
     lib = _lib.load()
@@ -116,6 +116,11 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
         ep.dropout = 1
         ep.seed, ep.site = seed, site
         ep.step_dev = step_dev.data_ptr(); keep.append(step_dev)
+        if drop_frame is not None:                # (origin, full edge): out0 is a window of a larger tensor
+            org, full = drop_frame
+            o3, d3 = _p3(org, is3d), _k3(full, is3d)
+            for i in range(3):
+                ep.drop_org[i], ep.drop_dims[i] = o3[i], d3[i]
     if transposed:
         fn = lib.tem_conv_transpose_direct if direct else lib.tem_conv_transpose
     else:
@@ -151,24 +156,53 @@ class GradWorkspace:
     def __init__(self, params, ncalls):
         self.params, self.ncalls, self.buf = params, ncalls, {}
         self.flip_rows = {}        # layer -> row length: slab rows are stored in reversed tap order
+        self.requests = {}         # layer -> list of (call, nslab, args struct or 1-D view holder)
+        self.final = False
 
-    def slabs(self, layer, call, nslab):
+    def _size(self, layer):
         size = 1
         for d in self.params.shapes[layer]:
             size *= d
-        t = self.buf.get(layer)
-        if t is None:
-            t = self.buf[layer] = torch.zeros((self.ncalls, nslab, size), dtype=torch.float32,
-                                              device=self.params.theta.device)
-        assert t.shape[1] == nslab, (layer, t.shape, nslab)
-        return t[call]
+        return size
+
+    def request(self, layer, call, nslab, args=None, patch=None):
+        """Register a weight-gradient pass; its slab pointer is patched in by finalize() (passes of one
+        layer may need different slab counts: the cycle-path calls run on smaller regions)."""
+        assert not self.final
+        self.requests.setdefault(layer, []).append((call, nslab, args if patch is None else patch))
+
+    def finalize(self):
+        if self.final:
+            return
+        self.final = True
+        for layer, reqs in self.requests.items():
+            size, total = self._size(layer), sum(n for _, n, _ in reqs)
+            t = self.buf[layer] = torch.zeros((total, size), dtype=torch.float32, device=self.params.theta.device)
+            off = 0
+            for call, n, args in reqs:
+                if callable(args):
+                    args(t[off].data_ptr())
+                elif args is not None:
+                    args.slabs = t[off].data_ptr()
+                off += n
+
+    def slab_view(self, layer, call):
+        """1-D view of the first slab of (layer, call) -- for launches that write a slab directly."""
+        self.finalize()
+        off = 0
+        for c, n, _ in self.requests[layer]:
+            if c == call:
+                return self.buf[layer][off]
+            off += n
+        raise KeyError((layer, call))
 
     def reduce_launches(self, prefix):
         """ONE launch summing calls x slabs of every layer into the flat gradient vector."""
         lib = _lib.load()
+        self.finalize()
         items = []
         for layer, t in self.buf.items():
-            n, nsl = t.shape[2], t.shape[0] * t.shape[1]
+            n, nsl = t.shape[1], t.shape[0]
             out = self.params.g(layer)
             row = self.flip_rows.get(layer)
             if row:                 # C_out == 1 layers computed in swapped form: slab row r holds tap (ntap-1-r)
@@ -208,9 +242,8 @@ def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=
     n = lib.tem_conv_bwd_weight_nslab(C.byref(a))
     if n < 1:
         _lib.check(n, name + " (nslab query)")
-    slabs = ws.slabs(layer, call, n)
-    keep.append(slabs)
-    a.slabs = slabs.data_ptr()
+    ws.request(layer, call, n, a)           # a.slabs is patched by ws.finalize() (before the first run)
+    keep.append(ws)
     a.slab_stride = 0
     a.nslab = n
     a.accumulate = 0
@@ -236,6 +269,15 @@ def channel_sum_launch(name, g, out, accumulate=False):
     lib = _lib.load()
     v = view(g)
     return Launch(lib.tem_channel_sum, (C.byref(v), out.data_ptr(), int(accumulate)), name, [g, out, v])
+
+
+def bias_grad_launch(name, g, ws, layer, call):
+    """Bias gradient (sum over voxels) written into slab 0 of (layer, call) of a GradWorkspace."""
+    lib = _lib.load()
+    v = view(g)
+    launch = Launch(lib.tem_channel_sum, (C.byref(v), None, 0), name, [g, v, ws])
+    ws.request(layer, call, 1, patch=lambda ptr: setattr(launch, "args", (C.byref(v), ptr, 0)))
+    return launch
 
 
 def focal_logits_launch(name, z, target, gamma, losses, slot_mask, loss_scale, dz=None, grad_scale=1.0):

@@ -113,7 +113,7 @@ class DiscBackward:
             if need_dw:
                 L.append(H.bww_launch("d.bww." + name, xin, g_out, ws, name, call, k, s, 0, is3d=i3))
                 if name == "p2":
-                    L.append(H.channel_sum_launch("d.bias", g_out, ws.slabs("p2_bias", call, 1).view(-1)))
+                    L.append(H.bias_grad_launch("d.bias", g_out, ws, "p2_bias", call))
             if i == 0 and not need_dx:
                 break
             dst = G[order[i - 1]] if i > 0 else self.dx

@@ -70,47 +70,104 @@ def dropout_site(call_id, block):
     return call_id * 4 + block
 
 
-class GenForward:
-    """Activations + launches of one generator call site (static shapes)."""
+def _clip(r, edge):
+    return max(r[0], 0), min(r[1], edge)
 
-    def __init__(self, net, x, in_pad=0, training=False, drop=None, direct=False):
+
+def _union(a, b):
+    return min(a[0], b[0]), max(a[1], b[1])
+
+
+def needed_regions(n_eff, out_crop):
+    """Per-tensor [lo, hi) (full-tensor coordinates, same on every spatial axis) that must be computed
+    to obtain the output window [out_crop, out - out_crop).
+
+    The cycle path feeds zero-padded fakes and then crops the result by `buffer` (cgan.py:161-174): only
+    the central window of `cycled` reaches the loss, so only the receptive cone of that window has to be
+    evaluated -- the values inside the cone are the same numbers the full evaluation produces, and every
+    gradient is exactly zero outside it.  out_crop == 0 gives the full tensors."""
+    e = generator_edges(n_eff)
+    lo0, _ = skip_crop(e["d1a"], e["u1b"])
+    lo1, _ = skip_crop(e["d2a"], e["u2b"])
+    c3 = lambda r: (r[0], r[1] + 2)                      # input region of a k3 s1 VALID conv
+    c4 = lambda r: (2 * r[0], 2 * r[1] + 2)              # ... of a k4 s2 VALID conv
+    ct = lambda r: ((r[0] - 1) // 2, r[1] // 2 + 1)      # ... of ConvTranspose k4 s2 'same' (o = 2j + t - 1)
+    R = {}
+    R["f2"] = (out_crop, e["f2"] - out_crop)
+    R["f1"] = _clip(c3(R["f2"]), e["f1"])
+    R["u1b"] = _clip(c3(R["f1"]), e["u1b"])             # region of cat0 = [u1b | cropped skip0]
+    R["u1a"] = _clip(ct(R["u1b"]), e["u1a"])
+    R["mid"] = _clip(c3(R["u1a"]), e["mid"])
+    R["u2b"] = _clip(c3(R["mid"]), e["u2b"])             # region of cat1
+    R["u2a"] = _clip(ct(R["u2b"]), e["u2a"])
+    R["d2b"] = _clip(c3(R["u2a"]), e["d2b"])
+    R["d2a"] = _union(_clip(c4(R["d2b"]), e["d2a"]), (R["u2b"][0] + lo1, R["u2b"][1] + lo1))
+    R["d1b"] = _clip(c3(R["d2a"]), e["d1b"])
+    R["d1a"] = _union(_clip(c4(R["d1b"]), e["d1a"]), (R["u1b"][0] + lo0, R["u1b"][1] + lo0))
+    R["c0"] = _clip(c3(R["d1a"]), e["c0"])
+    return R
+
+
+def _window(t, start, size, is3d):
+    if is3d:
+        return t[:, start:start + size, start:start + size, start:start + size, :]
+    return t[:, :, start:start + size, start:start + size, :]
+
+
+class GenForward:
+    """Activations + launches of one generator call site (static shapes).
+
+    out_crop > 0 evaluates only what the central output window needs (see needed_regions); every
+    activation buffer then holds the region R[layer] of its logical tensor and the operators get the
+    correspondingly shifted padding (conv: p' = p + lo_in - s*lo_out, transposed: p' = p + lo_out - s*lo_in)."""
+
+    def __init__(self, net, x, in_pad=0, training=False, drop=None, out_crop=0, direct=False):
         P, is3d = net.params, net.is3d
         self.net, self.x, self.in_pad, self.training, self.drop = net, x, in_pad, training, drop
         N = x.shape[0]
         e = generator_edges(x.shape[3] + 2 * in_pad)
         self.edges = e
+        R = self.regions = needed_regions(x.shape[3] + 2 * in_pad, out_crop)
         ch = {k: s[-1] for k, s in P.shapes.items()}
         ch["u2b"], ch["u1b"] = P.shapes["u2b"][3], P.shapes["u1b"][3]
+        self.ch = ch
 
         def alloc(layer):
-            n = e[layer]
+            n = R[layer][1] - R[layer][0]
             return torch.empty((N, n if is3d else 1, n, n, ch[layer]), dtype=torch.float32, device=x.device)
 
         A = self.act = {k: alloc(k) for k in ("c0", "d1a", "d1b", "d2a", "d2b", "u2a", "u2b", "mid", "u1a", "u1b",
                                               "f1", "f2")}
-        self.lo1, hi1 = skip_crop(e["d2a"], e["u2b"])
-        self.lo0, hi0 = skip_crop(e["d1a"], e["u1b"])
-        self.skip1 = H.crop(A["d2a"], self.lo1, hi1, is3d)
-        self.skip0 = H.crop(A["d1a"], self.lo0, hi0, is3d)
+        self.lo1, _ = skip_crop(e["d2a"], e["u2b"])
+        self.lo0, _ = skip_crop(e["d1a"], e["u1b"])
+        lo = lambda k: R[k][0]
+        size = lambda k: R[k][1] - R[k][0]
+        # skip tensors windowed to exactly the region of the concat they feed
+        self.skip1 = _window(A["d2a"], lo("u2b") + self.lo1 - lo("d2a"), size("u2b"), is3d)
+        self.skip0 = _window(A["d1a"], lo("u1b") + self.lo0 - lo("d1a"), size("u1b"), is3d)
         dr = (lambda blk: (drop[0], dropout_site(drop[1], blk), drop[2])) if (training and drop) else (lambda blk: None)
         kw = dict(is3d=is3d, direct=direct)
+        pc = lambda p, s, i, o: p + lo(i) - s * lo(o) if i else p - s * lo(o)      # conv-like pad ('' = full input x)
+        pt = lambda p, s, i, o: p + lo(o) - s * lo(i)                               # transposed-conv pad
         L = self.launches = []
         cv = H.conv_launch
-        L.append(cv("g.c0", x, P.w("c0"), A["c0"], 3, 1, in_pad, slope=H.LEAKY, **kw))
-        L.append(cv("g.d1a", A["c0"], P.w("d1a"), A["d1a"], 3, slope=H.LEAKY, **kw))
-        L.append(cv("g.d1b", A["d1a"], P.w("d1b"), A["d1b"], 4, 2, slope=H.LEAKY, **kw))
-        L.append(cv("g.d2a", A["d1b"], P.w("d2a"), A["d2a"], 3, slope=H.LEAKY, **kw))
-        L.append(cv("g.d2b", A["d2a"], P.w("d2b"), A["d2b"], 4, 2, slope=H.LEAKY, **kw))
-        L.append(cv("g.u2a", A["d2b"], P.w("u2a"), A["u2a"], 3, slope=H.LEAKY, **kw))
-        L.append(cv("g.u2b", A["u2a"], P.w("u2b"), A["u2b"], 4, 2, 1, transposed=True, slope=H.LEAKY,
-                    dropout=dr(0), **kw))
-        L.append(cv("g.mid", A["u2b"], P.w("mid"), A["mid"], 3, in1=self.skip1, slope=H.LEAKY, **kw))
-        L.append(cv("g.u1a", A["mid"], P.w("u1a"), A["u1a"], 3, slope=H.LEAKY, **kw))
-        L.append(cv("g.u1b", A["u1a"], P.w("u1b"), A["u1b"], 4, 2, 1, transposed=True, slope=H.LEAKY,
-                    dropout=dr(1), **kw))
-        L.append(cv("g.f1", A["u1b"], P.w("f1"), A["f1"], 3, in1=self.skip0, slope=H.LEAKY, **kw))
-        L.append(cv("g.f2", A["f1"], P.w("f2"), A["f2"], 3, slope=1.0, **kw))
-        self.y = A["f2"]
+        L.append(cv("g.c0", x, P.w("c0"), A["c0"], 3, 1, pc(in_pad, 1, "", "c0"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d1a", A["c0"], P.w("d1a"), A["d1a"], 3, 1, pc(0, 1, "c0", "d1a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d1b", A["d1a"], P.w("d1b"), A["d1b"], 4, 2, pc(0, 2, "d1a", "d1b"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d2a", A["d1b"], P.w("d2a"), A["d2a"], 3, 1, pc(0, 1, "d1b", "d2a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d2b", A["d2a"], P.w("d2b"), A["d2b"], 4, 2, pc(0, 2, "d2a", "d2b"), slope=H.LEAKY, **kw))
+        L.append(cv("g.u2a", A["d2b"], P.w("u2a"), A["u2a"], 3, 1, pc(0, 1, "d2b", "u2a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.u2b", A["u2a"], P.w("u2b"), A["u2b"], 4, 2, pt(1, 2, "u2a", "u2b"), transposed=True,
+                    slope=H.LEAKY, dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]), **kw))
+        L.append(cv("g.mid", A["u2b"], P.w("mid"), A["mid"], 3, 1, pc(0, 1, "u2b", "mid"), in1=self.skip1,
+                    slope=H.LEAKY, **kw))
+        L.append(cv("g.u1a", A["mid"], P.w("u1a"), A["u1a"], 3, 1, pc(0, 1, "mid", "u1a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.u1b", A["u1a"], P.w("u1b"), A["u1b"], 4, 2, pt(1, 2, "u1a", "u1b"), transposed=True,
+                    slope=H.LEAKY, dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), **kw))
+        L.append(cv("g.f1", A["u1b"], P.w("f1"), A["f1"], 3, 1, pc(0, 1, "u1b", "f1"), in1=self.skip0,
+                    slope=H.LEAKY, **kw))
+        L.append(cv("g.f2", A["f1"], P.w("f2"), A["f2"], 3, 1, pc(0, 1, "f1", "f2"), slope=1.0, **kw))
+        self.y = A["f2"]                                   # window [out_crop, out - out_crop) of the logical output
 
     def run(self, stream=None):
         H.run(self.launches, stream)
@@ -118,24 +175,25 @@ class GenForward:
 
 
 class GenBackward:
-    """Adjoint of one GenForward: fills this call's kernel-gradient slabs and, if asked, dx."""
+    """Adjoint of one GenForward: fills this call's kernel-gradient slabs and, if asked, dx.
+    `dy` is the gradient w.r.t. fwd.y (the computed output window)."""
 
     def __init__(self, fwd, dy, ws, call, need_dx=False, direct=False):
-        net, A, e = fwd.net, fwd.act, fwd.edges
-        P, is3d = net.params, net.is3d
+        net, A, e, R = fwd.net, fwd.act, fwd.edges, fwd.regions
+        P, is3d, ch = net.params, net.is3d, fwd.ch
         N, dev = fwd.x.shape[0], fwd.x.device
         self.fwd, self.dy = fwd, dy
-        ch = {k: s[-1] for k, s in P.shapes.items()}
-        ch["u2b"], ch["u1b"] = P.shapes["u2b"][3], P.shapes["u1b"][3]
+        lo = lambda k: R[k][0]
 
         def alloc(layer, c=None):
-            n = e[layer]
+            n = R[layer][1] - R[layer][0]
             return torch.empty((N, n if is3d else 1, n, n, ch[layer] if c is None else c), dtype=torch.float32,
                                device=dev)
 
         G = self.grads = {k: alloc(k) for k in ("c0", "d1a", "d1b", "d2a", "d2b", "u2a", "u2b", "mid", "u1a", "u1b",
                                                 "f1")}
-        t_skip0 = alloc("u1b", ch["d1a"])          # raw gradient reaching the cropped skip0
+        G["f2"] = dy
+        t_skip0 = alloc("u1b", ch["d1a"])          # raw gradient reaching the cropped skip0 (cat0 region)
         t_skip1 = alloc("u2b", ch["d2a"])
         self.dx = torch.empty_like(fwd.x) if need_dx else None
         dr = (lambda blk: (fwd.drop[0], dropout_site(fwd.drop[1], blk), fwd.drop[2])) \
@@ -143,40 +201,49 @@ class GenBackward:
         kw = dict(is3d=is3d, direct=direct)
         FL, AS = H.TEM_W_FLIP_CO_CI, H.TEM_W_TAP_CI_CO
         cv = H.conv_launch
+        pc = lambda p, s, i, o: p + lo(i) - s * lo(o)       # conv-like op reading tensor i, writing tensor o
+        pt = lambda p, s, i, o: p + lo(o) - s * lo(i)       # transposed-conv-like op
 
-        def bww(name, in0, dout, k, s=1, p=0, in1=None):
+        def bww(name, in0, dout, k, s, p, in1=None):
             return H.bww_launch("g.bww." + name, in0, dout, ws, name, call, k, s, p, is3d=is3d, in1=in1)
 
         L = self.launches = []
-        L.append(bww("f2", A["f1"], dy, 3))
-        L.append(cv("g.bd.f2", dy, P.w("f2"), G["f1"], 3, 1, 2, layout=FL, gate=A["f1"], **kw))
-        L.append(bww("f1", A["u1b"], G["f1"], 3, in1=fwd.skip0))
-        L.append(cv("g.bd.f1", G["f1"], P.w("f1"), G["u1b"], 3, 1, 2, layout=FL, out1=t_skip0, gate=A["u1b"],
-                    dropout=dr(1), **kw))
-        L.append(bww("u1b", G["u1b"], A["u1a"], 4, 2, 1))
-        L.append(cv("g.bd.u1b", G["u1b"], P.w("u1b"), G["u1a"], 4, 2, 1, layout=AS, gate=A["u1a"], **kw))
-        L.append(bww("u1a", A["mid"], G["u1a"], 3))
-        L.append(cv("g.bd.u1a", G["u1a"], P.w("u1a"), G["mid"], 3, 1, 2, layout=FL, gate=A["mid"], **kw))
-        L.append(bww("mid", A["u2b"], G["mid"], 3, in1=fwd.skip1))
-        L.append(cv("g.bd.mid", G["mid"], P.w("mid"), G["u2b"], 3, 1, 2, layout=FL, out1=t_skip1, gate=A["u2b"],
-                    dropout=dr(0), **kw))
-        L.append(bww("u2b", G["u2b"], A["u2a"], 4, 2, 1))
-        L.append(cv("g.bd.u2b", G["u2b"], P.w("u2b"), G["u2a"], 4, 2, 1, layout=AS, gate=A["u2a"], **kw))
-        L.append(bww("u2a", A["d2b"], G["u2a"], 3))
-        L.append(cv("g.bd.u2a", G["u2a"], P.w("u2a"), G["d2b"], 3, 1, 2, layout=FL, gate=A["d2b"], **kw))
-        L.append(bww("d2b", A["d2a"], G["d2b"], 4, 2))
-        L.append(cv("g.bd.d2b", G["d2b"], P.w("d2b"), G["d2a"], 4, 2, 0, transposed=True, add=t_skip1,
-                    add_off=fwd.lo1, gate=A["d2a"], **kw))
-        L.append(bww("d2a", A["d1b"], G["d2a"], 3))
-        L.append(cv("g.bd.d2a", G["d2a"], P.w("d2a"), G["d1b"], 3, 1, 2, layout=FL, gate=A["d1b"], **kw))
-        L.append(bww("d1b", A["d1a"], G["d1b"], 4, 2))
-        L.append(cv("g.bd.d1b", G["d1b"], P.w("d1b"), G["d1a"], 4, 2, 0, transposed=True, add=t_skip0,
-                    add_off=fwd.lo0, gate=A["d1a"], **kw))
-        L.append(bww("d1a", A["c0"], G["d1a"], 3))
-        L.append(cv("g.bd.d1a", G["d1a"], P.w("d1a"), G["c0"], 3, 1, 2, layout=FL, gate=A["c0"], **kw))
-        L.append(bww("c0", fwd.x, G["c0"], 3, 1, fwd.in_pad))
+        # every input-gradient of a stride-1 VALID conv is a conv with pad k-1 = 2 over the output gradient
+        L.append(bww("f2", A["f1"], dy, 3, 1, pc(0, 1, "f1", "f2")))
+        L.append(cv("g.bd.f2", dy, P.w("f2"), G["f1"], 3, 1, pc(2, 1, "f2", "f1"), layout=FL, gate=A["f1"], **kw))
+        L.append(bww("f1", A["u1b"], G["f1"], 3, 1, pc(0, 1, "u1b", "f1"), in1=fwd.skip0))
+        L.append(cv("g.bd.f1", G["f1"], P.w("f1"), G["u1b"], 3, 1, pc(2, 1, "f1", "u1b"), layout=FL, out1=t_skip0,
+                    gate=A["u1b"], dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), **kw))
+        L.append(bww("u1b", G["u1b"], A["u1a"], 4, 2, pc(1, 2, "u1b", "u1a")))
+        L.append(cv("g.bd.u1b", G["u1b"], P.w("u1b"), G["u1a"], 4, 2, pc(1, 2, "u1b", "u1a"), layout=AS,
+                    gate=A["u1a"], **kw))
+        L.append(bww("u1a", A["mid"], G["u1a"], 3, 1, pc(0, 1, "mid", "u1a")))
+        L.append(cv("g.bd.u1a", G["u1a"], P.w("u1a"), G["mid"], 3, 1, pc(2, 1, "u1a", "mid"), layout=FL,
+                    gate=A["mid"], **kw))
+        L.append(bww("mid", A["u2b"], G["mid"], 3, 1, pc(0, 1, "u2b", "mid"), in1=fwd.skip1))
+        L.append(cv("g.bd.mid", G["mid"], P.w("mid"), G["u2b"], 3, 1, pc(2, 1, "mid", "u2b"), layout=FL, out1=t_skip1,
+                    gate=A["u2b"], dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]), **kw))
+        L.append(bww("u2b", G["u2b"], A["u2a"], 4, 2, pc(1, 2, "u2b", "u2a")))
+        L.append(cv("g.bd.u2b", G["u2b"], P.w("u2b"), G["u2a"], 4, 2, pc(1, 2, "u2b", "u2a"), layout=AS,
+                    gate=A["u2a"], **kw))
+        L.append(bww("u2a", A["d2b"], G["u2a"], 3, 1, pc(0, 1, "d2b", "u2a")))
+        L.append(cv("g.bd.u2a", G["u2a"], P.w("u2a"), G["d2b"], 3, 1, pc(2, 1, "u2a", "d2b"), layout=FL,
+                    gate=A["d2b"], **kw))
+        L.append(bww("d2b", A["d2a"], G["d2b"], 4, 2, pc(0, 2, "d2a", "d2b")))
+        L.append(cv("g.bd.d2b", G["d2b"], P.w("d2b"), G["d2a"], 4, 2, pt(0, 2, "d2b", "d2a"), transposed=True,
+                    add=t_skip1, add_off=lo("u2b") + fwd.lo1 - lo("d2a"), gate=A["d2a"], **kw))
+        L.append(bww("d2a", A["d1b"], G["d2a"], 3, 1, pc(0, 1, "d1b", "d2a")))
+        L.append(cv("g.bd.d2a", G["d2a"], P.w("d2a"), G["d1b"], 3, 1, pc(2, 1, "d2a", "d1b"), layout=FL,
+                    gate=A["d1b"], **kw))
+        L.append(bww("d1b", A["d1a"], G["d1b"], 4, 2, pc(0, 2, "d1a", "d1b")))
+        L.append(cv("g.bd.d1b", G["d1b"], P.w("d1b"), G["d1a"], 4, 2, pt(0, 2, "d1b", "d1a"), transposed=True,
+                    add=t_skip0, add_off=lo("u1b") + fwd.lo0 - lo("d1a"), gate=A["d1a"], **kw))
+        L.append(bww("d1a", A["c0"], G["d1a"], 3, 1, pc(0, 1, "c0", "d1a")))
+        L.append(cv("g.bd.d1a", G["d1a"], P.w("d1a"), G["c0"], 3, 1, pc(2, 1, "d1a", "c0"), layout=FL,
+                    gate=A["c0"], **kw))
+        L.append(bww("c0", fwd.x, G["c0"], 3, 1, fwd.in_pad - lo("c0")))        # x is the full input tensor
         if need_dx:
-            L.append(cv("g.bd.c0", G["c0"], P.w("c0"), self.dx, 3, 1, 2 - fwd.in_pad, layout=FL, **kw))
+            L.append(cv("g.bd.c0", G["c0"], P.w("c0"), self.dx, 3, 1, 2 - fwd.in_pad + lo("c0"), layout=FL, **kw))
         self._keep = (t_skip0, t_skip1)
 
     def run(self, stream=None):
