@@ -51,7 +51,9 @@ def build(name, direct=False):
     if kind == "bd":
         return H.conv_launch(name, y, w, x, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI, gate=torch.randn_like(x), direct=direct)
     ws = H.GradWorkspace(_P((k, k, k, CI, CO)), 1)
-    return H.bww_launch(name, x, y, ws, "w", 0, k, s, 0)
+    l = H.bww_launch(name, x, y, ws, "w", 0, k, s, 0)
+    ws.finalize()
+    return l
 
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]

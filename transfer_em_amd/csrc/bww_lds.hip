@@ -50,10 +50,14 @@ struct Cfg {
   static constexpr int MTILES = (ROWS + 15) / 16;
   static constexpr int NT = (CO + 15) / 16;
   static constexpr int T = MTILES * NT;
-  static constexpr int TPW = (T + NW - 1) / NW;
+  // When there are fewer tiles than waves (C_in == 1: 2 tiles) the waves split the voxel rows instead:
+  // KSPL waves own the same tiles for interleaved rows and are summed through LDS at the end.
+  static constexpr int KSPL = (T * 2 <= NW) ? NW / ((T + NT - 1) / NT * NT) : 1;
+  static constexpr int WG = NW / KSPL;                    // wave groups = distinct tile owners
+  static constexpr int TPW = (T + WG - 1) / WG;
   static constexpr int CHX = CI % 4 == 0 ? 4 : 1;     // floats per loader chunk
   static constexpr int CHG = CO % 4 == 0 ? 4 : 1;
-  static_assert(NW % NT == 0, "a wave keeps one n-tile");
+  static_assert(NW % NT == 0 && WG % NT == 0 && NW % KSPL == 0, "a wave keeps one n-tile");
 };
 
 template <int CH>
@@ -188,13 +192,15 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
     }
   };
 
-  // ---- this wave's accumulator tiles: t = wave + j*NW, n-tile fixed per wave
-  const int nt = wave % NT;
+  // ---- this wave's accumulator tiles: t = wgid + j*WG, n-tile fixed per wave; kshare = which rows it sums
+  constexpr int WG = C::WG, KSPL = C::KSPL;
+  const int wgid = wave % WG, kshare = wave / WG;
+  const int nt = wgid % NT;
   int aconst[TPW], adz[TPW];
   f32x4 acc[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
-    int t = min(wave + j * NW, C::T - 1);                  // tiles past T: recomputed copy, never stored
+    int t = min(wgid + j * WG, C::T - 1);                  // tiles past T: recomputed copy, never stored
     int mt = t / NT;
     int row = min(mt * 16 + m, C::ROWS - 1);              // rows >= ROWS are never stored
     int tap = row / CI, ci = row - tap * CI;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
     // the next k-step are issued BEFORE the current k-step's MFMAs (sched_barrier pins that order),
     // so their latency hides under TPW back-to-back MFMAs.  OWp is a multiple of 8: nk is even.
     const int nk = p.OWp >> 2;
-    for (int r = 0; r < p.R; ++r) {
+    for (int r = kshare; r < p.R; r += KSPL) {
       const float *xr = Xs + r * S * rowpitch;
       const float *gr = Gs + r * growpitch + boff;
       float a0[TPW], a1[TPW], b0, b1;
@@ -285,18 +291,38 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
     __syncthreads();
   }
 
-  // ---- one partial slab per workgroup, each tile written by the wave that owns it
+  // ---- one partial slab per workgroup, each tile written by the wave group that owns it
+  if constexpr (KSPL > 1) {                                // sum the KSPL row shares through LDS (the ring is dead now)
+    float *red = lds;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[((wave * TPW + j) * 4 + q) * 64 + lane] = acc[j][q];
+    __syncthreads();
+    if (kshare == 0) {
+#pragma unroll
+      for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[j][q];
+          for (int ks = 1; ks < KSPL; ++ks) v += red[(((ks * WG + wgid) * TPW + j) * 4 + q) * 64 + lane];
+          acc[j][q] = v;
+        }
+    }
+  }
   float *slab = p.slabs + (int64_t)blockIdx.x * p.slab_stride;
+  if (kshare == 0) {
 #pragma unroll
-  for (int j = 0; j < TPW; ++j) {
-    int t = wave + j * NW;
-    if (t < C::T) {
-      int mt = t / NT;
-      int co = nt * 16 + m;
+    for (int j = 0; j < TPW; ++j) {
+      int t = wgid + j * WG;
+      if (t < C::T) {
+        int mt = t / NT;
+        int co = nt * 16 + m;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int row = mt * 16 + kq * 4 + q;                    // C/D map: row = 4*(lane>>4)+reg, col = lane&15
-        if (row < C::ROWS && co < CO) slab[(int64_t)row * CO + co] = acc[j][q];
+        for (int q = 0; q < 4; ++q) {
+          int row = mt * 16 + kq * 4 + q;                  // C/D map: row = 4*(lane>>4)+reg, col = lane&15
+          if (row < C::ROWS && co < CO) slab[(int64_t)row * CO + co] = acc[j][q];
+        }
       }
     }
   }
@@ -328,7 +354,12 @@ bool plan(Dev &p, int max_slabs, size_t &lds_bytes, int &nblocks) {
     size_t bytes = ((size_t)K * YR * p.WXp * C::CIP + (size_t)R * p.OWp * C::COP) * 4;
     bool fits = bytes <= (size_t)LDS_BUDGET && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * NTHR &&
                 (size_t)R * p.chunksG <= (size_t)MAXPFG * NTHR;
-    if (fits) { p.R = R; p.YR = YR; lds_bytes = (bytes + 15) & ~(size_t)15; break; }
+    if (fits) {
+      p.R = R; p.YR = YR;
+      size_t red = C::KSPL > 1 ? (size_t)NW * C::TPW * 4 * 64 * 4 : 0;   // the row-share reduction reuses the ring
+      lds_bytes = ((bytes > red ? bytes : red) + 15) & ~(size_t)15;
+      break;
+    }
   }
   if (R < 1) return false;
   p.nych = (p.OH + p.R - 1) / p.R;
@@ -401,7 +432,7 @@ int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
   };
   if (!aligned(i0) || (a->in1.ptr && !aligned(a->in1)) || !aligned(g)) return TEM_EUNSUPPORTED;
   //        CI  CO  K  S  waves  X-chunks  G-chunks     (tiles per wave = ceil(K^3*CI/16 * ceil(CO/16) / waves))
-  BWW_CASE(1, 8, 3, 1, 4, 6, 8)      // g.c0 / d.d1a: 2 tiles, HBM-bound on the gradient stream
+  BWW_CASE(1, 8, 3, 1, 8, 3, 4)      // g.c0 / d.d1a: 2 tiles x 4 row shares, HBM-bound on the gradient stream
   BWW_CASE(8, 8, 3, 1, 8, 4, 3)      // g.d1a: 14 tiles
   BWW_CASE(8, 16, 3, 1, 8, 4, 3)     // g.d2a / d.hack
   BWW_CASE(16, 16, 3, 1, 8, 4, 3)    // g.f1: 27 tiles, 4 per wave (two waves per SIMD hide LDS latency)
@@ -409,7 +440,7 @@ int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
   BWW_CASE(32, 32, 3, 1, 8, 5, 3)    // g.mid / d.d3a: 108 tiles, 14 per wave
   BWW_CASE(32, 16, 3, 1, 8, 5, 3)    // g.u1a: 54 tiles
   BWW_CASE(16, 1, 3, 1, 4, 8, 5)     // (kept for callers that do not use the swapped C_out = 1 form)
-  BWW_CASE(1, 16, 3, 1, 4, 6, 8)     // g.f2 swapped: X := dy (1 ch), G := f1 (16 ch), pad 2 -> dW with flipped taps
+  BWW_CASE(1, 16, 3, 1, 8, 3, 4)     // g.f2 swapped: X := dy (1 ch), G := f1 (16 ch), pad 2 -> dW with flipped taps
   BWW_CASE(8, 8, 4, 2, 8, 6, 2)      // g.d1b / d.d1b: 32 tiles
   BWW_CASE(16, 16, 4, 2, 8, 6, 3)    // g.d2b: 64 tiles
   BWW_CASE(8, 16, 4, 2, 8, 6, 2)     // g.u1b (transposed conv: roles of input and gradient swapped)
