@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--dimsize", type=int, default=132)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="run the step on one stream (kernel durations free of overlap: use under rocprofv3 to "
+                         "check roofline.avg_launch_us)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +100,8 @@ def main():
 
     from transfer_em_amd.cgan import EM2EM
     n, B = args.dimsize, args.batch
-    model = EM2EM(n, "bench", is3d=True, seed=42, checkpoint_root=os.path.join("/tmp", f"tem_bench_{os.getpid()}"))
+    model = EM2EM(n, "bench", is3d=True, seed=42, checkpoint_root=os.path.join("/tmp", f"tem_bench_{os.getpid()}"),
+                  two_streams=not args.single_stream)
     shape = (B, n, n, n)
     rx = torch.from_numpy(synthetic_volume(shape, 1234 + rank)).cuda()
     ry = torch.from_numpy(synthetic_volume(shape, 5678 + rank)).cuda()
@@ -125,8 +129,11 @@ def main():
     out = None
     if rank == 0:
         st = model._steps[B]
-        agg = per_kernel_profile(model, st, max(2, min(5, args.steps)), streams=True)
-        alone = per_kernel_profile(model, st, 2, streams=False)
+        nprof = max(2, min(5, args.steps))
+        # roofline of the dominant kernel: launches timed one at a time on the launch stream (no other kernel on
+        # the GPU); the same launches under the real 3-stream schedule are reported beside it
+        agg = per_kernel_profile(model, st, nprof, streams=False)
+        conc = per_kernel_profile(model, st, 2, streams=True) if model.two_streams else {}
         dom_k, dom = max(((k, v) for k, v in agg.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         secs = dom["ms"] * 1e-3
         ai = dom["flops"] / dom["bytes"]
@@ -136,7 +143,7 @@ def main():
             roof = dict(bound="hbm", achieved=dom["bytes"] / secs / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
         # HBM bytes per launch of this kernel from the PMC passes (profiles/collect_traffic.py; the counters
-        # cannot be read inside this process) -- null when that kernel/shape has not been profiled
+        # cannot be read inside this process) -- measured on the kernel's full-size launch; null if not profiled
         roof["traffic"] = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
@@ -149,13 +156,11 @@ def main():
         roof["kernel"] = dom_k
         roof["avg_launch_us"] = dom["ms"] * 1e3 / dom["launches"]
         roof["share_of_step"] = dom["ms"] / sum(v["ms"] for v in agg.values())
-        if dom_k in alone and alone[dom_k]["ms"] > 0:      # same kernel with nothing else on the GPU
-            a1 = alone[dom_k]
-            roof["standalone_avg_launch_us"] = a1["ms"] * 1e3 / a1["launches"]
-            roof["standalone_frac"] = ((a1["flops"] / (a1["ms"] * 1e-3) / 1e12) / FP32_PEAK_TFLOPS if roof["bound"] == "mfma"
-                                       else (a1["bytes"] / (a1["ms"] * 1e-3) / 1e9) / HBM_PEAK_GBS)
-        tot_flops = sum(v["flops"] for v in agg.values()) / max(2, min(5, args.steps))
-        tot_bytes = sum(v["bytes"] for v in agg.values()) / max(2, min(5, args.steps))
+        if dom_k in conc and conc[dom_k]["ms"] > 0:       # same launches while the other two streams are busy
+            roof["concurrent_avg_launch_us"] = conc[dom_k]["ms"] * 1e3 / conc[dom_k]["launches"]
+        alone = agg
+        tot_flops = sum(v["flops"] for v in agg.values()) / nprof
+        tot_bytes = sum(v["bytes"] for v in agg.values()) / nprof
         if args.kernel_table:
             for k, v in sorted(alone.items(), key=lambda kv: -kv[1]["ms"]):
                 s_ = v["ms"] * 1e-3
