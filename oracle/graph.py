@@ -409,7 +409,9 @@ def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, see
 
     aux = dict(fake_y=fake_y, fake_x=fake_x, cyc_x=cyc_x, cyc_y=cyc_y, same_x=same_x, same_y=same_y,
                z_rx=z_rx, z_ry=z_ry, z_fx=z_fx, z_fy=z_fy, sv_g1=sv_g1, buffer=b,
-               d_fake_y=d_fake_y, d_fake_x=d_fake_x)
+               d_fake_y=d_fake_y, d_fake_x=d_fake_x,
+               saved=dict(g1=sv_g1, f2=sv_f2, f1=sv_f1, g2=sv_g2, f3=sv_f3, g3=sv_g3,
+                          dxr=sv_dxr, dyr=sv_dyr, dxf=sv_dxf, dyf=sv_dyf))
     return losses, dict(g=grad_g, f=grad_f, dx=grad_dx, dy=grad_dy), aux
 
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import rel_err, scaled_params
+from util import gate_flips, rel_err, scaled_params
 
 pytestmark = pytest.mark.gpu
 
@@ -62,21 +62,23 @@ def test_train_step_matches_oracle(tmp_path, oracle_lib, is3d, batch, scaled):
                           ("same_y", "g3")):
             ref = crop(aux[key]) if key.startswith("cyc") else aux[key]      # cycled_*: only the cropped window exists
             assert rel_err(cs.fwd[plan].y.cpu().numpy(), ref) < 1e-4, key
-        assert rel_err(cs.bwd["f2"].dx.cpu().numpy(), aux["d_fake_y"]) < (5e-4 if is3d else 1e-4)
+        # gradients: tight when no LeakyReLU gate differs between the two forwards, see util.gate_flips
+        flips = gate_flips(cs, aux["saved"], is3d)
+        gtol = 1e-2 if flips else (2e-4 if is3d else 1e-4)
+        print(f"step {step}: {flips} gate flips, gradient tolerance {gtol:g}")
+        assert rel_err(cs.bwd["f2"].dx.cpu().numpy(), aux["d_fake_y"]) < gtol
         for net in ("g", "f", "dx", "dy"):
             for name, ref in grads[net].items():
                 scale = max(np.abs(v).max() for v in grads[net].values())
                 err = np.abs(grads_hip[net][name] - ref).max()
                 # the bias gradient is a sum of logit gradients of both signs: absolute floor from fp32 dz
                 floor = 1e-7 * scale + (3e-8 if name.endswith("_bias") else 0.0)
-                # 3-D kernel gradients are fp32 sums over 10^5..10^6 voxels with heavy cancellation: 5e-4
-                gtol = 5e-4 if is3d else 1e-4
                 assert err <= gtol * np.abs(ref).max() + floor, (step, net, name, err, np.abs(ref).max())
         for net, obj in zip(("g", "f", "dx", "dy"), model._nets):
             # Adam moments are linear / quadratic in g: tight relative check.  theta moves by ~lr per
             # step whatever |g| is (m/sqrt(v)), which amplifies relative gradient error where |g| ~ eps:
             # compare the parameters in units of lr.
-            for which, tol in (("m", 5e-4 if is3d else 1e-4), ("v", 1e-3 if is3d else 2e-4)):
+            for which, tol in (("m", gtol), ("v", 2 * gtol)):
                 got_s = obj.params.to_dict(which)
                 for name, ref in st[which][net].items():
                     scale = max(np.abs(v).max() for v in st[which][net].values())
@@ -92,6 +94,32 @@ def test_train_step_matches_oracle(tmp_path, oracle_lib, is3d, batch, scaled):
                 big = gref >= 1e-2 * gref.max()
                 assert np.abs(th[name] - st[net][name])[big].max() < 0.15 * 2e-4, (step, net, name)
                 assert np.abs(th[name] - st[net][name]).max() <= 2.05 * 2e-4, (step, net, name)
+
+
+def test_train_step_3d_batch2_one_step(tmp_path, oracle_lib):
+    """BASELINE config 3 uses a per-GPU batch of 2: batch-mean losses and gradients over two 3-D volumes."""
+    from oracle import graph
+    from transfer_em_amd.cgan import EM2EM
+    shape = (2, 74, 74, 74, 1)
+    rx, ry = _inputs(shape, 11), _inputs(shape, 12)
+    st = _state(graph, True, True)
+    model = EM2EM(74, "b2", checkpoint_root=str(tmp_path))
+    _load(model, st)
+    got = model.train_step(torch.from_numpy(rx), torch.from_numpy(ry)).cpu().numpy()
+    grads_hip = {k: net.params.to_dict("grad") for k, net in zip(("g", "f", "dx", "dy"), model._nets)}
+    losses, grads, aux = graph.train_step_grads(st["g"], st["f"], st["dx"], st["dy"], rx, ry, True, 2.0, 42, 0)
+    assert rel_err(got, losses) < 1e-5
+    cs = model._steps[2]
+    for key, plan in (("fake_y", "g1"), ("fake_x", "f1"), ("same_x", "f3"), ("same_y", "g3")):
+        assert rel_err(cs.fwd[plan].y.cpu().numpy(), aux[key]) < 1e-4, key
+    flips = gate_flips(cs, aux["saved"], True)
+    gtol = 1e-2 if flips else 2e-4
+    print(f"{flips} gate flips, gradient tolerance {gtol:g}")
+    for net in ("g", "f", "dx", "dy"):
+        scale = max(np.abs(v).max() for v in grads[net].values())
+        for name, ref in grads[net].items():
+            err = np.abs(grads_hip[net][name] - ref).max()
+            assert err <= gtol * np.abs(ref).max() + 1e-7 * scale + 3e-8, (net, name, err)
 
 
 def test_generator_inference_132(oracle_lib):

@@ -31,3 +31,32 @@ def scaled_params(shapes, seed, gain=1.0):
             std *= 0.05
         p[name] = (rng.standard_normal(shp) * std).astype(np.float32)
     return p
+
+
+_GEN_SAVED = dict(f1="f1", u1b="u1", u1a="b1", mid="m", u2b="u2", u2a="b2", d2b="d2", d2a="s1", d1b="d1", d1a="s0",
+                  c0="a0")
+_DISC_SAVED = dict(d1a="e1", d1b="e2", hack="h", d2a="e3", d2b="e4", d3a="e5", d3b="e6", p1="p1")
+
+
+def gate_flips(cs, saved, is3d=True):
+    """Number of LeakyReLU outputs whose SIGN differs between the HIP forward and the oracle forward.
+
+    LeakyReLU' is discontinuous at 0: an activation that is 1e-7 on one side and -1e-7 on the other (fp32
+    MFMA chain vs the oracle's double accumulation) scales that element's gradient by 0.3 instead of 1,
+    and the difference spreads to every kernel gradient below it.  One flip among ~10^6 elements already
+    shows as ~1e-4..1e-3 relative error, so the step-level gradient tolerance is tight only when this
+    returns 0.  `cs` is the compiled step (cgan._CompiledStep), `saved` is aux["saved"] of the oracle."""
+    n = 0
+    for call, sv in saved.items():
+        fwd = cs.fwd[call]
+        table = _GEN_SAVED if call[0] in "gf" else _DISC_SAVED
+        for layer, key in table.items():
+            if key not in sv or layer not in fwd.act:
+                continue
+            ref = sv[key]
+            if call[0] in "gf":
+                lo, hi = fwd.regions[layer]
+                ref = ref[:, lo:hi, lo:hi, lo:hi, :] if is3d else ref[:, :, lo:hi, lo:hi, :]
+            got = fwd.act[layer].cpu().numpy()
+            n += int(np.count_nonzero((got > 0) != (ref > 0)))
+    return n
