@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--dimsize", type=int, default=132)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--graph", action="store_true", help="replay the step as captured HIP graphs instead of eager launches")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the step on one stream (kernel durations free of overlap: use under rocprofv3 to "
                          "check roofline.avg_launch_us)")
@@ -101,7 +102,7 @@ def main():
     from transfer_em_amd.cgan import EM2EM
     n, B = args.dimsize, args.batch
     model = EM2EM(n, "bench", is3d=True, seed=42, checkpoint_root=os.path.join("/tmp", f"tem_bench_{os.getpid()}"),
-                  two_streams=not args.single_stream)
+                  two_streams=not args.single_stream, use_graph=True if args.graph else None)
     shape = (B, n, n, n)
     rx = torch.from_numpy(synthetic_volume(shape, 1234 + rank)).cuda()
     ry = torch.from_numpy(synthetic_volume(shape, 5678 + rank)).cuda()

@@ -15,7 +15,8 @@ if "--stamps" in sys.argv:       # diagnostic build path: per-phase cycle sums o
 rnd = lambda *s: torch.randn(*s, device=dev, dtype=torch.float32)
 # name: (CI, CO, k, s, in_edge)
 GEOM = dict(f1=(16, 16, 3, 1, 100), mid=(32, 32, 3, 1, 54), d1a=(8, 8, 3, 1, 130), u1a=(32, 16, 3, 1, 52),
-            d1b=(8, 8, 4, 2, 128), f2=(16, 1, 3, 1, 98), c0=(1, 8, 3, 1, 132))
+            d1b=(8, 8, 4, 2, 128), f2=(16, 1, 3, 1, 98), c0=(1, 8, 3, 1, 132), d2a=(8, 16, 3, 1, 64),
+            D2b=(32, 32, 4, 2, 42), g2b=(16, 16, 4, 2, 62), u2b=(32, 16, 4, 2, 26), u1b=(16, 8, 4, 2, 50))
 
 
 class _P:
@@ -32,6 +33,10 @@ def build(name, direct=False):
     kind, layer = ("fwd", name)
     if name.startswith("bdd_"):          # input-gradient through Dropout with split outputs (g.bd.f1 / g.bd.mid)
         kind, layer = "bdd", name[4:]
+    elif name.startswith("bdt_"):        # input-gradient of a k4 s2 conv (transposed-conv kernel)
+        kind, layer = "bdt", name[4:]
+    elif name.startswith("ct_"):         # Conv3DTranspose forward (k4 s2 'same')
+        kind, layer = "ct", name[3:]
     elif name.startswith("bd_"):
         kind, layer = "bd", name[3:]
     elif name.startswith("bww_"):
@@ -48,6 +53,12 @@ def build(name, direct=False):
         step = torch.zeros(1, dtype=torch.int32, device=dev)
         return H.conv_launch(name, y, w, o0, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI, out1=o1, gate=torch.randn_like(o0),
                              dropout=(42, 1, step), direct=direct)
+    if kind == "bdt":
+        return H.conv_launch(name, y, w, x, k, s, 0, transposed=True, gate=torch.randn_like(x), direct=direct)
+    if kind == "ct":
+        up = rnd(1, 2 * n, 2 * n, 2 * n, CO)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        return H.conv_launch(name, x, w, up, k, s, 1, transposed=True, slope=0.3, dropout=(42, 1, step), direct=direct)
     if kind == "bd":
         return H.conv_launch(name, y, w, x, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI, gate=torch.randn_like(x), direct=direct)
     ws = H.GradWorkspace(_P((k, k, k, CI, CO)), 1)

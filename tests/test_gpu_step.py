@@ -122,6 +122,23 @@ def test_train_step_3d_batch2_one_step(tmp_path, oracle_lib):
             assert err <= gtol * np.abs(ref).max() + 1e-7 * scale + 3e-8, (net, name, err)
 
 
+def test_graph_replay_equals_eager(tmp_path):
+    """use_graph=True replays the captured three-stream step: same kernels, same order constraints,
+    bit-identical losses and parameters (every kernel is deterministic)."""
+    from transfer_em_amd.cgan import EM2EM
+    shape = (1, 74, 74, 74, 1)
+    rx, ry = torch.from_numpy(_inputs(shape, 3)), torch.from_numpy(_inputs(shape, 4))
+    out = []
+    for graph_mode in (False, True):
+        model = EM2EM(74, f"graph{int(graph_mode)}", checkpoint_root=str(tmp_path), use_graph=graph_mode)
+        losses = [model.train_step(rx, ry).cpu().numpy() for _ in range(4)]     # eager, capture+replay, replay, replay
+        assert (model._steps[1].graphs is not None) == graph_mode
+        out.append((np.stack(losses), [net.params.theta.cpu().numpy() for net in model._nets]))
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+
+
 def test_generator_inference_132(oracle_lib):
     """EM2EM.predict == generator_g in inference mode (dropout off), at the benchmark size."""
     from oracle import graph

@@ -9,6 +9,8 @@
 // wave-uniform and come through s_load.  Bounds (padding / crop) are handled by predicated
 // loads, never by divergent control flow.
 #include "tem_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -51,7 +53,12 @@ __device__ __forceinline__ void store_vec(float *p, const float (&v)[C]) {
 }
 
 // acc[co] += sum_ci xv[ci] * W(ci, co); wt points at the tap's C_in x C_out block.
-// FLIP: block is stored [co][ci] (TEM_W_FLIP_CO_CI / transposed-conv layout), else [ci][co].
+// COCI: block is stored [co][ci] (TEM_W_FLIP_CO_CI / transposed-conv layout), else [ci][co].
+// The accumulator is kept as PAIRS so that the compiler can issue v_pk_fma_f32 (two fp32 FMAs per
+// lane-instruction) with a pair of ADJACENT scalar-loaded weights as one operand:
+//   [ci][co] layout: the pair is (co, co+1) of one ci            -> acc pair = two output channels;
+//   [co][ci] layout: the pair is (ci, ci+1) of one co            -> acc pair = even-ci / odd-ci partial
+//                                                                   sums of ONE output channel (ACC2).
 template <int CIP, int CI, int CO, bool COCI>
 __device__ __forceinline__ void fma_block(float (&acc)[CO], const float (&xv)[CIP], const float *wt, int ci_base) {
 #pragma unroll
@@ -60,6 +67,20 @@ __device__ __forceinline__ void fma_block(float (&acc)[CO], const float (&xv)[CI
     for (int co = 0; co < CO; ++co) {
       float wv = COCI ? wt[co * CI + ci_base + ci] : wt[(ci_base + ci) * CO + co];
       acc[co] = fmaf(xv[ci], wv, acc[co]);
+    }
+  }
+}
+
+// [co][ci] layout with split accumulators: acc2[2*co] sums the even input channels, acc2[2*co+1] the odd ones
+template <int CIP, int CI, int CO>
+__device__ __forceinline__ void fma_block_split(float (&acc2)[2 * CO], const float (&xv)[CIP], const float *wt, int ci_base) {
+  static_assert(CIP % 2 == 0, "pairs of input channels");
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+#pragma unroll
+    for (int ci = 0; ci < CIP; ci += 2) {
+      acc2[2 * co] = fmaf(xv[ci], wt[co * CI + ci_base + ci], acc2[2 * co]);
+      acc2[2 * co + 1] = fmaf(xv[ci + 1], wt[co * CI + ci_base + ci + 1], acc2[2 * co + 1]);
     }
   }
 }
@@ -83,15 +104,17 @@ __device__ __forceinline__ void finish(const ConvDev &p, float (&acc)[CO0 + CO1]
 template <int CI0, int CI1, int CO0, int CO1, bool FLIP>
 __global__ __launch_bounds__(256) void conv_direct_k(ConvDev p) {
   constexpr int CI = CI0 + CI1, CO = CO0 + CO1;
+  constexpr bool SPLIT = FLIP && CI0 % 2 == 0 && CI1 % 2 == 0;     // see fma_block_split
+  constexpr int NACC = SPLIT ? 2 * CO : CO;
   int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= p.total) return;
   int x = (int)(idx % p.OW); int64_t r = idx / p.OW;
   int y = (int)(r % p.OH); r /= p.OH;
   int z = (int)(r % p.OD); int n = (int)(r / p.OD);
 
-  float acc[CO];
+  float acc[NACC];
 #pragma unroll
-  for (int i = 0; i < CO; ++i) acc[i] = 0.f;
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
 
   const int ntap = p.kd * p.kh * p.kw;
   int tap = 0;
@@ -107,16 +130,25 @@ __global__ __launch_bounds__(256) void conv_direct_k(ConvDev p) {
         const float *wt = p.w + (int64_t)(FLIP ? ntap - 1 - tap : tap) * (CI * CO);
         float xv[CI0];
         load_vec<CI0>(xv, p.in0 + n * p.i0N + iz * p.i0D + iy * p.i0H + ix * p.i0W, ok);
-        fma_block<CI0, CI, CO, FLIP>(acc, xv, wt, 0);
+        if constexpr (SPLIT) fma_block_split<CI0, CI, CO>(acc, xv, wt, 0);
+        else fma_block<CI0, CI, CO, FLIP>(acc, xv, wt, 0);
         if constexpr (CI1 > 0) {
           float xw[CI1];
           load_vec<CI1>(xw, p.in1 + n * p.i1N + iz * p.i1D + iy * p.i1H + ix * p.i1W, ok);
-          fma_block<CI1, CI, CO, FLIP>(acc, xw, wt, CI0);
+          if constexpr (SPLIT) fma_block_split<CI1, CI, CO>(acc, xw, wt, CI0);
+          else fma_block<CI1, CI, CO, FLIP>(acc, xw, wt, CI0);
         }
       }
     }
   }
-  finish<CO0, CO1>(p, acc, n, z, y, x);
+  if constexpr (SPLIT) {
+    float out[CO];
+#pragma unroll
+    for (int i = 0; i < CO; ++i) out[i] = acc[2 * i] + acc[2 * i + 1];
+    finish<CO0, CO1>(p, out, n, z, y, x);
+  } else {
+    finish<CO0, CO1>(p, acc, n, z, y, x);
+  }
 }
 
 // ------------------------------------------------------------------ transposed conv
@@ -136,9 +168,11 @@ __global__ __launch_bounds__(256) void convT_direct_k(ConvDev p) {
   int qz = (int)(r % QD); int n = (int)(r / QD);
   int x = qx * p.sw + rx, y = qy * p.sh + ry, z = qz * p.sd + rz;
 
-  float acc[CO];
+  constexpr bool SPLIT = CI0 % 2 == 0;                 // see fma_block_split
+  constexpr int NACC = SPLIT ? 2 * CO : CO;
+  float acc[NACC];
 #pragma unroll
-  for (int i = 0; i < CO; ++i) acc[i] = 0.f;
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
 
   // taps with t == (o + p) mod s; j = (o + p - t) / s
   int tz0 = (rz + p.pd) % p.sd, ty0 = (ry + p.ph) % p.sh, tx0 = (rx + p.pw) % p.sw;
@@ -155,11 +189,19 @@ __global__ __launch_bounds__(256) void convT_direct_k(ConvDev p) {
         const float *wt = p.w + (int64_t)tap * (CI * CO);
         float xv[CI0];
         load_vec<CI0>(xv, p.in0 + n * p.i0N + jz * p.i0D + jy * p.i0H + jx * p.i0W, ok);
-        fma_block<CI0, CI, CO, true>(acc, xv, wt, 0);
+        if constexpr (SPLIT) fma_block_split<CI0, CI, CO>(acc, xv, wt, 0);
+        else fma_block<CI0, CI, CO, true>(acc, xv, wt, 0);
       }
     }
   }
-  finish<CO0, CO1>(p, acc, n, z, y, x);
+  if constexpr (SPLIT) {
+    float out[CO];
+#pragma unroll
+    for (int i = 0; i < CO; ++i) out[i] = acc[2 * i] + acc[2 * i + 1];
+    finish<CO0, CO1>(p, out, n, z, y, x);
+  } else {
+    finish<CO0, CO1>(p, acc, n, z, y, x);
+  }
 }
 
 int fill_dev(const tem_conv_args *a, ConvDev &p, bool transposed) {
@@ -212,16 +254,18 @@ int fill_dev(const tem_conv_args *a, ConvDev &p, bool transposed) {
     return TEM_OK;                                                                            \
   }
 
-extern "C" int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream) {
-  TEM_CLEAR_ERR();
+static int conv_direct_impl(const tem_conv_args *a, hipStream_t st, char *name, int name_len) {
   ConvDev p{};
   int rc = fill_dev(a, p, false);
   if (rc) return rc;
   const int CI0 = a->in0.C, CI1 = a->in1.ptr ? a->in1.C : 0;
   const int CO0 = a->out0.C, CO1 = a->out1.ptr ? a->out1.C : 0;
   const bool flip = a->w_layout == TEM_W_FLIP_CO_CI;
-  hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((p.total + 255) / 256));
+  if (name) {
+    snprintf(name, name_len, "conv_direct_k<%d, %d, %d, %d, %s>", CI0, CI1, CO0, CO1, flip ? "true" : "false");
+    return TEM_OK;
+  }
   // forward shapes
   CONV_CASE(1, 0, 8, 0) CONV_CASE(1, 0, 16, 0) CONV_CASE(1, 0, 32, 0)
   CONV_CASE(8, 0, 8, 0) CONV_CASE(8, 0, 16, 0) CONV_CASE(8, 0, 1, 0)
@@ -231,6 +275,15 @@ extern "C" int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream) {
   // split outputs (input-gradient through a concat)
   CONV_CASE(16, 0, 8, 8) CONV_CASE(32, 0, 16, 16)
   return TEM_EUNSUPPORTED;
+}
+
+extern "C" int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  return conv_direct_impl(a, (hipStream_t)stream, nullptr, 0);
+}
+
+int tem_conv_direct_describe(const tem_conv_args *a, char *name, int len) {
+  return conv_direct_impl(a, nullptr, name, len);
 }
 
 #define CONVT_CASE(ci0, co0, co1)                                                       \

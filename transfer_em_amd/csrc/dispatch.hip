@@ -19,12 +19,15 @@ extern "C" int tem_conv_transpose(const tem_conv_args *a, tem_stream_t stream) {
 
 int tem_conv_lds_describe(const tem_conv_args *a, char *buf, int len);      // conv_lds.hip
 int tem_bww_lds_describe(const tem_bww_args *a, char *buf, int len);        // bww_lds.hip
+int tem_conv_direct_describe(const tem_conv_args *a, char *name, int len);  // conv_direct.hip
 
 extern "C" int tem_conv_is_tiled(const tem_conv_args *a, int32_t transposed, char *name, int32_t name_len) {
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->out0) || !a->w) return TEM_EINVAL;
   if (name && name_len > 0) name[0] = 0;
   if (transposed) return 0;
-  return tem_conv_lds_describe(a, name, name_len) == TEM_OK ? 1 : 0;
+  if (tem_conv_lds_describe(a, name, name_len) == TEM_OK) return 1;
+  if (name && name_len > 0) tem_conv_direct_describe(a, name, name_len);   // name of the direct kernel that will run
+  return 0;
 }
 
 extern "C" int tem_bww_is_tiled(const tem_bww_args *a, char *name, int32_t name_len) {

@@ -42,7 +42,10 @@ struct DropoutStream {
     return philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), site, step, k0, k1);
   }
   __device__ __forceinline__ static bool bit(const Philox128 &p, uint32_t e_in_block) {
-    return (p.r[(e_in_block >> 5) & 3] >> (e_in_block & 31)) & 1u;
+    // select chain, not p.r[i]: a runtime-indexed register array would be placed in scratch memory
+    const uint32_t i = (e_in_block >> 5) & 3u;
+    const uint32_t w = i == 0 ? p.r[0] : (i == 1 ? p.r[1] : (i == 2 ? p.r[2] : p.r[3]));
+    return (w >> (e_in_block & 31)) & 1u;
   }
 };
 

@@ -132,7 +132,7 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
     ci, co = ci0 + ci1, co0 + co1
     namebuf = C.create_string_buffer(96)
     tiled = (not direct) and lib.tem_conv_is_tiled(C.byref(a), int(transposed), namebuf, 96) == 1
-    if tiled:
+    if tiled or (namebuf.value and not direct and not transposed):
         kern = namebuf.value.decode()
     elif transposed:
         kern = f"convT_direct_k<{ci0}, {co0}, {co1}>"
