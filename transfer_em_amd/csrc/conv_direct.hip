@@ -151,6 +151,82 @@ __global__ __launch_bounds__(256) void conv_direct_k(ConvDev p) {
   }
 }
 
+// ------------------------------------------------------------------ conv, NY output rows per lane
+// The gather kernel above is bound by L1 bandwidth, not by FMA issue: per tap a wave pulls 64 x C_in
+// floats through the texture path for 64 x C_in x C_out FMAs.  Here a lane owns NY vertically adjacent
+// output voxels (same x, rows y0 .. y0+NY-1): an input row is loaded ONCE and feeds every output row
+// whose kernel window covers it, so the loads per output drop from KH to (KH + (NY-1)*SH) / NY rows
+// (3 -> 2 for a 3-tap kernel at NY = 2, 3 -> 1.5 at NY = 4) while lanes still read dense runs along x.
+template <int CI0, int CI1, int CO0, int CO1, bool FLIP, int KH, int SH, int NY>
+__global__ __launch_bounds__(256) void conv_rows_k(ConvDev p) {
+  constexpr int CI = CI0 + CI1, CO = CO0 + CO1, NR = KH + (NY - 1) * SH;
+  constexpr bool SPLIT = FLIP && CI0 % 2 == 0 && CI1 % 2 == 0;
+  constexpr int NACC = SPLIT ? 2 * CO : CO;
+  const int QH = (p.OH + NY - 1) / NY;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)p.N * p.OD * QH * p.OW) return;
+  int x = (int)(idx % p.OW); int64_t r_ = idx / p.OW;
+  int yq = (int)(r_ % QH); r_ /= QH;
+  int z = (int)(r_ % p.OD); int n = (int)(r_ / p.OD);
+  const int y0 = yq * NY;
+
+  float acc[NY][NACC];
+#pragma unroll
+  for (int v = 0; v < NY; ++v)
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[v][i] = 0.f;
+
+  const int ntap = p.kd * KH * p.kw;
+  const int iy_first = y0 * SH - p.ph;
+  for (int dz = 0; dz < p.kd; ++dz) {
+    int iz = z * p.sd + dz - p.pd;
+    bool okz = iz >= 0 && iz < p.D;
+    const float *pl0 = p.in0 + n * p.i0N + iz * p.i0D;
+    const float *pl1 = CI1 > 0 ? p.in1 + n * p.i1N + iz * p.i1D : nullptr;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      int iy = iy_first + r;
+      bool oky = okz && iy >= 0 && iy < p.H;
+      for (int dx = 0; dx < p.kw; ++dx) {
+        int ix = x * p.sw + dx - p.pw;
+        bool ok = oky && ix >= 0 && ix < p.W;
+        float xv[CI0];
+        load_vec<CI0>(xv, pl0 + iy * p.i0H + ix * p.i0W, ok);
+        float xw[CI1 > 0 ? CI1 : 1];
+        if constexpr (CI1 > 0) load_vec<CI1>(xw, pl1 + iy * p.i1H + ix * p.i1W, ok);
+#pragma unroll
+        for (int v = 0; v < NY; ++v) {
+          constexpr int dummy = 0; (void)dummy;
+          const int dy = r - v * SH;                       // compile-time after unrolling
+          if (dy >= 0 && dy < KH) {
+            const int tap = (dz * KH + dy) * p.kw + dx;
+            const float *wt = p.w + (int64_t)(FLIP ? ntap - 1 - tap : tap) * (CI * CO);
+            if constexpr (SPLIT) fma_block_split<CI0, CI, CO>(acc[v], xv, wt, 0);
+            else fma_block<CI0, CI, CO, FLIP>(acc[v], xv, wt, 0);
+            if constexpr (CI1 > 0) {
+              if constexpr (SPLIT) fma_block_split<CI1, CI, CO>(acc[v], xw, wt, CI0);
+              else fma_block<CI1, CI, CO, FLIP>(acc[v], xw, wt, CI0);
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NY; ++v) {
+    if (y0 + v < p.OH) {
+      if constexpr (SPLIT) {
+        float out[CO];
+#pragma unroll
+        for (int i = 0; i < CO; ++i) out[i] = acc[v][2 * i] + acc[v][2 * i + 1];
+        finish<CO0, CO1>(p, out, n, z, y0 + v, x);
+      } else {
+        finish<CO0, CO1>(p, acc[v], n, z, y0 + v, x);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ transposed conv
 // One launch covers all output residue classes (blockIdx.y); inside a class every lane uses
 // the same taps, so the weights stay wave-uniform.  out[o] = sum_{j,t: o = j*s + t - p}.
@@ -254,6 +330,16 @@ int fill_dev(const tem_conv_args *a, ConvDev &p, bool transposed) {
     return TEM_OK;                                                                            \
   }
 
+// row-blocked kernel: the full-resolution 8-channel / 1-channel layers of both networks
+#define ROWS_CASE(ci0, co0, fl, kh_, sh_, ny_)                                                            \
+  if (CI0 == ci0 && CI1 == 0 && CO0 == co0 && CO1 == 0 && flip == fl && a->kh == kh_ && a->sh == sh_) {  \
+    if (name) { snprintf(name, name_len, "conv_rows_k<%d, 0, %d, 0, %s, %d, %d, %d>", ci0, co0, fl ? "true" : "false", kh_, sh_, ny_); return TEM_OK; } \
+    const int64_t cnt = (int64_t)p.N * p.OD * ((p.OH + ny_ - 1) / ny_) * p.OW;                           \
+    hipLaunchKernelGGL((conv_rows_k<ci0, 0, co0, 0, fl, kh_, sh_, ny_>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, p); \
+    TEM_CHECK_LAUNCH();                                                                                   \
+    return TEM_OK;                                                                                        \
+  }
+
 static int conv_direct_impl(const tem_conv_args *a, hipStream_t st, char *name, int name_len) {
   ConvDev p{};
   int rc = fill_dev(a, p, false);
@@ -262,6 +348,18 @@ static int conv_direct_impl(const tem_conv_args *a, hipStream_t st, char *name, 
   const int CO0 = a->out0.C, CO1 = a->out1.ptr ? a->out1.C : 0;
   const bool flip = a->w_layout == TEM_W_FLIP_CO_CI;
   dim3 grid((unsigned)((p.total + 255) / 256));
+  {
+    // measured on MI355X (tests/microbench.py, 132^3 layer sizes): the row-blocked kernel wins where C_in or
+    // C_out is 1 and for the forward 8->8 layer; the [co][ci]-layout 8/16-channel cases and the strided
+    // layer stay on conv_direct_k (TEM_ROWS=0 disables it for A/B runs)
+    static int rows = -1;
+    if (rows < 0) { const char *v = getenv("TEM_ROWS"); rows = v ? atoi(v) : 1; }
+    if (rows && p.OH >= 16) {
+      ROWS_CASE(8, 8, false, 3, 1, 4)
+      ROWS_CASE(1, 8, false, 3, 1, 4) ROWS_CASE(8, 1, true, 3, 1, 4)
+      ROWS_CASE(16, 1, false, 3, 1, 4) ROWS_CASE(1, 16, true, 3, 1, 4)
+    }
+  }
   if (name) {
     snprintf(name, name_len, "conv_direct_k<%d, %d, %d, %d, %s>", CI0, CI1, CO0, CO1, flip ? "true" : "false");
     return TEM_OK;
