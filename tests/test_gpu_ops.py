@@ -34,6 +34,8 @@ FWD_CASES = [  # (CI, CO, k, s, pad, edge, is3d)
     (16, 16, 3, 1, 0, 11, True), (16, 1, 3, 1, 0, 14, True), (32, 32, 1, 1, 0, 5, True), (32, 1, 1, 1, 0, 5, True),
     (32, 32, 4, 2, 0, 10, True), (1, 8, 3, 1, 5, 10, True), (1, 16, 3, 1, 0, 30, False), (16, 32, 3, 1, 0, 20, False),
     (32, 32, 4, 2, 0, 21, False),
+    # row-blocked direct kernel (conv_rows_k: output height >= 16, not a multiple of its 4-row block)
+    (16, 1, 3, 1, 0, 21, True), (8, 8, 3, 1, 2, 17, True), (1, 8, 3, 1, 0, 24, False),
 ]
 
 
@@ -70,7 +72,8 @@ def test_conv_concat_and_crop_views(H, oracle_lib):
 
 
 BWD_CASES = [(8, 8, 3, 1, 12), (8, 16, 3, 1, 10), (16, 32, 3, 1, 8), (32, 32, 3, 1, 8), (16, 1, 3, 1, 12),
-             (1, 8, 3, 1, 12), (32, 32, 1, 1, 5)]
+             (1, 8, 3, 1, 12), (32, 32, 1, 1, 5),
+             (16, 1, 3, 1, 19), (1, 8, 3, 1, 21)]          # conv_rows_k: 1 -> 16 and 8 -> 1 input gradients
 
 
 @pytest.mark.parametrize("CI,CO,k,s,n", BWD_CASES)

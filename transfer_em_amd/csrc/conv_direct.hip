@@ -230,9 +230,15 @@ __global__ __launch_bounds__(256) void conv_rows_k(ConvDev p) {
 // ------------------------------------------------------------------ transposed conv
 // One launch covers all output residue classes (blockIdx.y); inside a class every lane uses
 // the same taps, so the weights stay wave-uniform.  out[o] = sum_{j,t: o = j*s + t - p}.
-template <int CI0, int CO0, int CO1>
+// CPT = output channels per thread: CO (one thread per voxel) or a slice of it (blockIdx.z picks the
+// slice).  The 32-channel layers of the discriminators are tiny (8^3 .. 42^3 voxels): one thread per
+// voxel leaves most CUs idle behind a serial chain of 8 x 32 x 32 FMAs fed by scalar loads, so those
+// run with 8 channels per thread and four times the threads.
+template <int CI0, int CO0, int CO1, int CPT>
 __global__ __launch_bounds__(256) void convT_direct_k(ConvDev p) {
   constexpr int CI = CI0, CO = CO0 + CO1;
+  static_assert(CPT == CO || (CO1 == 0 && CO % CPT == 0), "channel slices only without a split output");
+  const int cbase = CPT == CO ? 0 : blockIdx.z * CPT;
   int cls = blockIdx.y;
   int rx = cls % p.sw, ry = (cls / p.sw) % p.sh, rz = cls / (p.sw * p.sh);
   int QW = (p.OW - rx + p.sw - 1) / p.sw, QH = (p.OH - ry + p.sh - 1) / p.sh, QD = (p.OD - rz + p.sd - 1) / p.sd;
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256) void convT_direct_k(ConvDev p) {
   int x = qx * p.sw + rx, y = qy * p.sh + ry, z = qz * p.sd + rz;
 
   constexpr bool SPLIT = CI0 % 2 == 0;                 // see fma_block_split
-  constexpr int NACC = SPLIT ? 2 * CO : CO;
+  constexpr int NACC = SPLIT ? 2 * CPT : CPT;
   float acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
@@ -262,21 +268,22 @@ __global__ __launch_bounds__(256) void convT_direct_k(ConvDev p) {
         int jx = (x + p.pw - dx) / p.sw;
         bool ok = oky && (x + p.pw - dx) >= 0 && jx < p.W;
         int tap = (dz * p.kh + dy) * p.kw + dx;
-        const float *wt = p.w + (int64_t)tap * (CI * CO);
+        const float *wt = p.w + (int64_t)tap * (CI * CO) + cbase * CI;       // [co][ci] block, this thread's rows
         float xv[CI0];
         load_vec<CI0>(xv, p.in0 + n * p.i0N + jz * p.i0D + jy * p.i0H + jx * p.i0W, ok);
-        if constexpr (SPLIT) fma_block_split<CI0, CI, CO>(acc, xv, wt, 0);
-        else fma_block<CI0, CI, CO, true>(acc, xv, wt, 0);
+        if constexpr (SPLIT) fma_block_split<CI0, CI, CPT>(acc, xv, wt, 0);
+        else fma_block<CI0, CI, CPT, true>(acc, xv, wt, 0);
       }
     }
   }
-  if constexpr (SPLIT) {
-    float out[CO];
+  float out[CPT];
 #pragma unroll
-    for (int i = 0; i < CO; ++i) out[i] = acc[2 * i] + acc[2 * i + 1];
+  for (int i = 0; i < CPT; ++i) out[i] = SPLIT ? acc[2 * i] + acc[2 * i + 1] : acc[i];
+  if constexpr (CPT == CO) {
     finish<CO0, CO1>(p, out, n, z, y, x);
   } else {
-    finish<CO0, CO1>(p, acc, n, z, y, x);
+    apply_epilogue<CPT>(p.ep, out, n, z, y, x, cbase, p.OD, p.OH, p.OW, CO);
+    store_vec<CPT>(p.out0 + n * p.o0N + z * p.o0D + y * p.o0H + x * p.o0W + cbase, out);
   }
 }
 
@@ -384,11 +391,12 @@ int tem_conv_direct_describe(const tem_conv_args *a, char *name, int len) {
   return conv_direct_impl(a, nullptr, name, len);
 }
 
-#define CONVT_CASE(ci0, co0, co1)                                                       \
-  if (CI0 == ci0 && CO0 == co0 && CO1 == co1) {                                         \
-    hipLaunchKernelGGL((convT_direct_k<ci0, co0, co1>), grid, dim3(256), 0, st, p);     \
-    TEM_CHECK_LAUNCH();                                                                 \
-    return TEM_OK;                                                                      \
+#define CONVT_CASE(ci0, co0, co1, cpt)                                                                  \
+  if (CI0 == ci0 && CO0 == co0 && CO1 == co1) {                                                         \
+    dim3 g(grid.x, grid.y, (unsigned)((co0 + co1) / cpt));                                              \
+    hipLaunchKernelGGL((convT_direct_k<ci0, co0, co1, cpt>), g, dim3(256), 0, st, p);                   \
+    TEM_CHECK_LAUNCH();                                                                                 \
+    return TEM_OK;                                                                                      \
   }
 
 extern "C" int tem_conv_transpose_direct(const tem_conv_args *a, tem_stream_t stream) {
@@ -403,7 +411,7 @@ extern "C" int tem_conv_transpose_direct(const tem_conv_args *a, tem_stream_t st
   int ncls = a->sd * a->sh * a->sw;
   int64_t qmax = (int64_t)p.N * ((p.OD + a->sd - 1) / a->sd) * ((p.OH + a->sh - 1) / a->sh) * ((p.OW + a->sw - 1) / a->sw);
   dim3 grid((unsigned)((qmax + 255) / 256), (unsigned)ncls);
-  CONVT_CASE(32, 16, 0) CONVT_CASE(16, 8, 0)                       // Conv3DTranspose forward
-  CONVT_CASE(8, 8, 0) CONVT_CASE(16, 16, 0) CONVT_CASE(32, 32, 0)  // input-grad of the k4 s2 convs
+  CONVT_CASE(32, 16, 0, 16) CONVT_CASE(16, 8, 0, 8)                           // Conv3DTranspose forward
+  CONVT_CASE(8, 8, 0, 8) CONVT_CASE(16, 16, 0, 16) CONVT_CASE(32, 32, 0, 8)   // input-grad of the k4 s2 convs
   return TEM_EUNSUPPORTED;
 }

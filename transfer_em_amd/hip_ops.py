@@ -135,7 +135,7 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
     if tiled or (namebuf.value and not direct and not transposed):
         kern = namebuf.value.decode()
     elif transposed:
-        kern = f"convT_direct_k<{ci0}, {co0}, {co1}>"
+        kern = f"convT_direct_k<{ci0}, {co0}, {co1}, {8 if co0 + co1 == 32 else co0 + co1}>"
     else:
         kern = f"conv_direct_k<{ci0}, {ci1}, {co0}, {co1}, {'true' if layout == TEM_W_FLIP_CO_CI else 'false'}>"
     meta = dict(flops=2.0 * ntap * ci * co * (vin if transposed else vout),
