@@ -142,7 +142,10 @@ class _CompiledStep:
         side += [loss[0], loss[1]] + loss[6:10] + L_(a_dy, a_dx) + [("record", "adv")]
         side += L_(w_dxr, w_dxf, w_dyr, w_dyf) + red["dx"] + red["dy"] + [("record", "side_done")]
         # main: generator G call sites; third: generator F call sites (their kernels overlap in the
-        # ramp-up / ramp-down of each other's grids)
+        # ramp-up / ramp-down of each other's grids).  Measured and rejected (MI355X, 132^3): moving the
+        # generators' kernel-gradient launches to two more streams (16.4 vs 15.75 ms/step -- the extra
+        # LDS-bound kernels only steal CUs from the dependent chains) and HIP stream priorities for the
+        # chains (17.9 ms/step).
         main += L_(f_g1) + [("record", "fake_y")] + L_(f_g3) + [("wait", "fake_x")] + L_(f_g2)
         third += [("wait", "inputs")] + L_(f_f1) + [("record", "fake_x")] + L_(f_f3) + [("wait", "fake_y")] + L_(f_f2)
         main += [loss[3], loss[4]] + L_(b_g3, b_g2) + [("record", "d_fake_x")]
@@ -151,9 +154,9 @@ class _CompiledStep:
         third += [("wait", "adv"), ("wait", "d_fake_x"), add_x] + L_(b_f1) + red["f"] + [("record", "third_done")]
         main += [("wait", "side_done"), ("wait", "third_done")]
         self.lists = (main, side, third)
-        self.extra_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-        self.events = {k: torch.cuda.Event() for k in ("inputs", "fake_y", "fake_x", "adv", "side_done", "d_fake_x",
-                                                       "d_fake_y", "third_done", "joined")}
+        self.extra_streams = tuple(torch.cuda.Stream(device=dev) for _ in range(len(self.lists) - 1))
+        names = {"inputs", "joined"} | {it[1] for l in self.lists for it in l if isinstance(it, tuple)}
+        self.events = {k: torch.cuda.Event() for k in names}
         self._hops = []
 
         # ---- optimizer (cgan.py:218-228); gradients are averaged over ranks by grad_scale
@@ -311,7 +314,7 @@ class EM2EM(object):
         cur = torch.cuda.current_stream()
         st.events["inputs"].record(cur)              # losses cleared + inputs copied
         streams = [cur] + list(st.extra_streams)
-        used = [True, False, False]
+        used = [True] + [False] * (len(streams) - 1)
         its = [iter(l) for l in st.lists]
         pending = [None] * len(its)
         done = [False] * len(its)
