@@ -231,6 +231,10 @@ int tem_copy_view(const tem_view *src, const tem_view *dst, tem_stream_t stream)
 /* dst(view) += src(view) */
 int tem_add_view(const tem_view *src, const tem_view *dst, tem_stream_t stream);
 
+/* g(view) = saved(view) > 0 ? g : slope * g, in place: LeakyReLU gradient gated on the saved output where no
+ * convolution epilogue can carry it (gradient entering the frozen prior network, discriminator.py:62-66). */
+int tem_leaky_gate_view(const tem_view *g, const tem_view *saved, float slope, tem_stream_t stream);
+
 /* Library identification: returns TEM_ABI_VERSION; *arch (if non-NULL) receives a
  * static string naming the compiled offload target ("gfx950"). */
 int tem_abi_version(const char **arch);

@@ -71,11 +71,15 @@ def generator_param_shapes(is3d=True, wf=8):
     ])
 
 
-def discriminator_param_shapes(is3d=True, wf=8):
+def discriminator_param_shapes(is3d=True, wf=8, prior_channels=0):
     """discriminator.py:39-99.  3-D requires wf == 8; the 2-D graph never uses
-    Downsample_1 (the HACK conv is fed the raw input, discriminator.py:49-51)."""
+    Downsample_1 (the HACK conv is fed the raw input, discriminator.py:49-51).
+    prior_channels: channels of disc_prior's output, concatenated before Downsample_3
+    (discriminator.py:62-66: dims = 64, i.e. the prior must deliver 32 channels)."""
     if wf != 8:
         raise RuntimeError("discriminator graph is only consistent for wf == 8")
+    if prior_channels not in (0, 32):
+        raise RuntimeError("disc_prior must output 32 channels (Downsample_3 is built for dims = 64)")
     k3 = (3, 3, 3) if is3d else (1, 3, 3)
     k4 = (4, 4, 4) if is3d else (1, 4, 4)
     k1 = (1, 1, 1)
@@ -88,7 +92,7 @@ def discriminator_param_shapes(is3d=True, wf=8):
         s["hack"] = k3 + (1, 16)
     s["d2a"] = k3 + (16, 32)
     s["d2b"] = k4 + (32, 32)
-    s["d3a"] = k3 + (32, 32)
+    s["d3a"] = k3 + (32 + prior_channels, 32)
     s["d3b"] = k4 + (32, 32)
     s["p1"] = k1 + (32, 32)
     s["p2"] = k1 + (32, 1)
@@ -236,11 +240,37 @@ def generator_backward(P, sv, dy, need_dx=False):
 DOUBLE_LEAKY = np.float32(0.3) * np.float32(0.3)
 
 
-def discriminator_forward(P, x, is3d=True):
-    """discriminator graph (discriminator.py:14-105), disc_prior=None."""
+def prior_forward(prior, x, is3d=True):
+    """Frozen prior network (cgan.py:21-30 create_prior_helper: a Keras model cut at `last_layer`,
+    trainable=False), restated as a chain of VALID convolutions, each a tuple
+    (kernel (kd,kh,kw,Cin,Cout), bias or None, stride, LeakyReLU alpha or 1.0 for none).
+    Returns (features, [layer outputs])."""
+    acts, h = [], x
+    for w, b, stride, alpha in prior:
+        h = ops.conv_fwd(h, w, _stride(is3d, stride), _pad(is3d, 0), bias=b)
+        if alpha != 1.0:
+            h = ops.leaky_relu(h, alpha)
+        acts.append(h)
+    return h, acts
+
+
+def prior_backward_data(prior, acts, x_shape, g, is3d=True):
+    """Gradient of the prior's output w.r.t. its input (the weights are frozen but the generator's
+    adversarial gradient flows through the prior to fake_y)."""
+    for i in range(len(prior) - 1, -1, -1):
+        w, b, stride, alpha = prior[i]
+        if alpha != 1.0:
+            g = ops.leaky_relu_grad_from_out(g, acts[i], alpha)
+        in_shape = acts[i - 1].shape if i > 0 else x_shape
+        g = ops.conv_bwd_data(g, w, in_shape, _stride(is3d, stride), _pad(is3d, 0))
+    return g
+
+
+def discriminator_forward(P, x, is3d=True, prior=None):
+    """discriminator graph (discriminator.py:14-105); prior: see prior_forward (disc_prior, :62-66)."""
     S, Pd = (lambda s: _stride(is3d, s)), (lambda p: _pad(is3d, p))
     lr = ops.leaky_relu
-    sv = {"x": x, "is3d": is3d}
+    sv = {"x": x, "is3d": is3d, "prior": prior}
     if is3d:
         e1 = lr(ops.conv_fwd(x, P["d1a"], S(1), Pd(0)))
         e2 = lr(ops.conv_fwd(e1, P["d1b"], S(2), Pd(0)))
@@ -250,7 +280,15 @@ def discriminator_forward(P, x, is3d=True):
         h = lr(ops.conv_fwd(x, P["hack"], S(1), Pd(0)))             # F8: raw input
     e3 = lr(ops.conv_fwd(h, P["d2a"], S(1), Pd(0)))
     e4 = lr(ops.conv_fwd(e3, P["d2b"], S(2), Pd(0)))
-    e5 = lr(ops.conv_fwd(e4, P["d3a"], S(1), Pd(0)))
+    cat = e4
+    if prior is not None:
+        feat, pacts = prior_forward(prior, x, is3d)                     # x2 = disc_prior(inp)
+        if feat.shape[:4] != e4.shape[:4]:
+            raise RuntimeError(f"disc_prior output {feat.shape} does not match Downsample_2 output {e4.shape}")
+        cat = np.concatenate([e4, feat], axis=-1)                       # Concatenate()([x, x2])
+        sv.update(pacts=pacts)
+    sv["cat"] = cat
+    e5 = lr(ops.conv_fwd(cat, P["d3a"], S(1), Pd(0)))
     # Downsample_3's trailing LeakyReLU followed by discriminator.py:74's second one
     e6 = lr(lr(ops.conv_fwd(e5, P["d3b"], S(2), Pd(0))))
     p1 = lr(ops.conv_fwd(e6, P["p1"], S(1), Pd(0)))
@@ -283,8 +321,14 @@ def discriminator_backward(P, sv, dz, need_dx=False, need_dw=True):
     g_e6 = _gate2(ops.conv_bwd_data(g_p1, P["p1"], sv["e6"].shape, S(1), Pd(0)), sv["e6"])
     bw("d3b", sv["e5"], g_e6, k4, 2)
     g_e5 = gate(ops.conv_bwd_data(g_e6, P["d3b"], sv["e5"].shape, S(2), Pd(0)), sv["e5"])
-    bw("d3a", sv["e4"], g_e5, k3, 1)
-    g_e4 = gate(ops.conv_bwd_data(g_e5, P["d3a"], sv["e4"].shape, S(1), Pd(0)), sv["e4"])
+    bw("d3a", sv["cat"], g_e5, k3, 1)
+    g_cat = ops.conv_bwd_data(g_e5, P["d3a"], sv["cat"].shape, S(1), Pd(0))
+    c4 = sv["e4"].shape[-1]
+    g_e4 = gate(g_cat[..., :c4], sv["e4"])
+    dx_prior = None
+    if sv.get("prior") is not None and need_dx:
+        dx_prior = prior_backward_data(sv["prior"], sv["pacts"], sv["x"].shape,
+                                       np.ascontiguousarray(g_cat[..., c4:]), is3d)
     bw("d2b", sv["e3"], g_e4, k4, 2)
     g_e3 = gate(ops.conv_bwd_data(g_e4, P["d2b"], sv["e3"].shape, S(2), Pd(0)), sv["e3"])
     bw("d2a", sv["h"], g_e3, k3, 1)
@@ -302,6 +346,8 @@ def discriminator_backward(P, sv, dz, need_dx=False, need_dw=True):
         bw("hack", sv["x"], g_h, k3, 1)
         if need_dx:
             dx = ops.conv_bwd_data(g_h, P["hack"], sv["x"].shape, S(1), Pd(0))
+    if dx is not None and dx_prior is not None:
+        dx = (dx + dx_prior).astype(np.float32)
     grads = OrderedDict((k, G[k]) for k in P.keys()) if need_dw else None
     return grads, dx
 
@@ -341,7 +387,7 @@ def unflatten(vec, like):
     return out
 
 
-def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, seed=42, step=0,
+def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, seed=42, step=0, prior_y=None,
                      training=True):
     """Forward + losses + the four gradient sets of EM2EM.train_step (cgan.py:144-215).
 
@@ -366,9 +412,9 @@ def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, see
     cyc_x_c, cyc_y_c = cr(cyc_x, b), cr(cyc_y, b)
 
     z_rx, sv_dxr = discriminator_forward(Pdx, x_c, is3d)
-    z_ry, sv_dyr = discriminator_forward(Pdy, y_c, is3d)
+    z_ry, sv_dyr = discriminator_forward(Pdy, y_c, is3d, prior_y)       # only discriminator_y gets disc_prior (cgan.py:59)
     z_fx, sv_dxf = discriminator_forward(Pdx, fake_x, is3d)
-    z_fy, sv_dyf = discriminator_forward(Pdy, fake_y, is3d)
+    z_fy, sv_dyf = discriminator_forward(Pdy, fake_y, is3d, prior_y)
 
     gen_g, dz_gen_g = generator_loss(z_fy, gamma)
     gen_f, dz_gen_f = generator_loss(z_fx, gamma)
@@ -415,13 +461,13 @@ def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, see
     return losses, dict(g=grad_g, f=grad_f, dx=grad_dx, dy=grad_dy), aux
 
 
-def train_step(state, real_x, real_y, is3d=True, gamma=2.0, seed=42):
+def train_step(state, real_x, real_y, is3d=True, gamma=2.0, seed=42, prior_y=None):
     """Full EM2EM.train_step incl. the four simultaneous Keras-Adam updates (cgan.py:218-228).
 
     state: dict with params 'g','f','dx','dy' (OrderedDicts), adam 'm','v' per net (same
     structure, zeros initially) and integer 'step' (number of updates already applied)."""
     losses, grads, aux = train_step_grads(state["g"], state["f"], state["dx"], state["dy"],
-                                          real_x, real_y, is3d, gamma, seed, state["step"])
+                                          real_x, real_y, is3d, gamma, seed, state["step"], prior_y=prior_y)
     t = state["step"] + 1
     for net in ("g", "f", "dx", "dy"):
         for k in state[net]:
@@ -432,10 +478,11 @@ def train_step(state, real_x, real_y, is3d=True, gamma=2.0, seed=42):
     return losses, grads, aux
 
 
-def new_state(is3d=True, wf=8, seeds=(0, 1, 2, 3)):
+def new_state(is3d=True, wf=8, seeds=(0, 1, 2, 3), prior_channels=0):
     gs, ds = generator_param_shapes(is3d, wf), discriminator_param_shapes(is3d, wf)
+    dsy = discriminator_param_shapes(is3d, wf, prior_channels)
     st = dict(g=init_params(gs, seeds[0]), f=init_params(gs, seeds[1]),
-              dx=init_params(ds, seeds[2]), dy=init_params(ds, seeds[3]), step=0)
+              dx=init_params(ds, seeds[2]), dy=init_params(dsy, seeds[3]), step=0)
     zeros = lambda P: OrderedDict((k, np.zeros_like(v)) for k, v in P.items())
     st["m"] = {n: zeros(st[n]) for n in ("g", "f", "dx", "dy")}
     st["v"] = {n: zeros(st[n]) for n in ("g", "f", "dx", "dy")}

@@ -86,7 +86,19 @@ def generator(P, x, is3d=True, keep=None):
     return F.conv3d(f1, _w(P["f2"]))
 
 
-def discriminator(P, x, is3d=True):
+def prior_features(prior, x, is3d=True):
+    """Frozen disc_prior (cgan.py:21-30): chain of (kernel, bias, stride, alpha) VALID convolutions."""
+    h = x
+    for w, b, stride, alpha in prior:
+        wt = _w(torch.as_tensor(np.asarray(w), dtype=x.dtype))
+        bt = None if b is None else torch.as_tensor(np.asarray(b), dtype=x.dtype)
+        h = F.conv3d(h, wt, bias=bt, stride=_st(is3d, stride))
+        if alpha != 1.0:
+            h = _lr(h, float(np.float32(alpha)))
+    return h
+
+
+def discriminator(P, x, is3d=True, prior=None):
     if is3d:
         e1 = _lr(F.conv3d(x, _w(P["d1a"])))
         e2 = _lr(F.conv3d(e1, _w(P["d1b"]), stride=_st(is3d, 2)))
@@ -95,6 +107,8 @@ def discriminator(P, x, is3d=True):
         h = _lr(F.conv3d(x, _w(P["hack"])))
     e3 = _lr(F.conv3d(h, _w(P["d2a"])))
     e4 = _lr(F.conv3d(e3, _w(P["d2b"]), stride=_st(is3d, 2)))
+    if prior is not None:
+        e4 = torch.cat([e4, prior_features(prior, x, is3d)], 1)          # discriminator.py:62-66
     e5 = _lr(F.conv3d(e4, _w(P["d3a"])))
     e6 = _lr(_lr(F.conv3d(e5, _w(P["d3b"]), stride=_st(is3d, 2))))
     p1 = _lr(F.conv3d(e6, _w(P["p1"])))
@@ -151,15 +165,15 @@ def _keeps(real_shape_ndhwc, P, call_id, seed, step, is3d, dtype):
 
 
 def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, seed=42, step=0,
-                     dtype=torch.float64, literal=True):
+                     dtype=torch.float64, literal=True, prior_y=None):
     """cgan.py:144-215 on autograd.  literal=True issues the reference's four gradient
     calls; literal=False uses the 2-sweep equivalent (the timed baseline).  NDHWC numpy in."""
     tg, tf_, tdx, tdy = (to_torch(p, dtype) for p in (Pg, Pf, Pdx, Pdy))
     return _step_core(tg, tf_, tdx, tdy, _ncdhw(real_x, dtype), _ncdhw(real_y, dtype),
-                      np.asarray(real_x).shape, is3d, gamma, seed, step, dtype, literal)
+                      np.asarray(real_x).shape, is3d, gamma, seed, step, dtype, literal, prior_y)
 
 
-def _step_core(tg, tf_, tdx, tdy, rx, ry, shape_ndhwc, is3d, gamma, seed, step, dtype, literal):
+def _step_core(tg, tf_, tdx, tdy, rx, ry, shape_ndhwc, is3d, gamma, seed, step, dtype, literal, prior_y=None):
     n = shape_ndhwc[3]
     b = (n - graph.generator_out(n)) // 2
     K = lambda call, P: _keeps(shape_ndhwc, P, call, seed, step, is3d, dtype)
@@ -173,9 +187,9 @@ def _step_core(tg, tf_, tdx, tdy, rx, ry, shape_ndhwc, is3d, gamma, seed, step, 
     same_y = generator(tg, ry, is3d, K(graph.CALL_G_SAME_Y, tg))
 
     z_rx = discriminator(tdx, cr(rx, b), is3d)
-    z_ry = discriminator(tdy, cr(ry, b), is3d)
+    z_ry = discriminator(tdy, cr(ry, b), is3d, prior_y)
     z_fx = discriminator(tdx, fake_x, is3d)
-    z_fy = discriminator(tdy, fake_y, is3d)
+    z_fy = discriminator(tdy, fake_y, is3d, prior_y)
 
     gen_g = generator_loss(z_fy, gamma)
     gen_f = generator_loss(z_fx, gamma)

@@ -60,3 +60,26 @@ def gate_flips(cs, saved, is3d=True):
             got = fwd.act[layer].cpu().numpy()
             n += int(np.count_nonzero((got > 0) != (ref > 0)))
     return n
+
+
+def prior_layers(is3d, seed=5, extra_tail=True):
+    """A frozen prior in the layer-list form of transfer_em_amd.models.prior (shaped like the
+    discriminator trunk up to Downsample_2 so that its output matches, discriminator.py:62-66).
+    With extra_tail the list continues past the cut point, as a full classifier would."""
+    rng = np.random.default_rng(seed)
+    kd = lambda k: (k if is3d else 1, k, k)
+    conv = lambda k, ci, co, s=1, bias=False, gain=1.0: {
+        "type": "conv", "kernel": (rng.standard_normal(kd(k) + (ci, co)) * gain / np.sqrt(k ** (3 if is3d else 2) * ci)
+                                   ).astype(np.float32),
+        "bias": (rng.standard_normal(co) * 0.1).astype(np.float32) if bias else None, "stride": s}
+    act = lambda a=0.3: {"type": "leaky_relu", "alpha": a}
+    L = [{"type": "input"}]
+    if is3d:
+        L += [conv(3, 1, 8, gain=2.0), act(), conv(4, 8, 8, 2, bias=True, gain=2.0), act(), conv(3, 8, 16, gain=2.0), act(0.2)]
+    else:
+        L += [conv(3, 1, 16, gain=2.0), act()]
+    L += [conv(3, 16, 24, bias=True, gain=2.0), act(), conv(4, 24, 32, 2, gain=2.0), act(0.1)]     # 24: off the channel table
+    cut = len(L) - 1
+    if extra_tail:
+        L += [conv(3, 32, 8), act()]
+    return L, cut

@@ -176,6 +176,16 @@ class _CompiledStep:
         return self._hops[:n]
 
 
+def create_prior_helper(prior_path, last_layer):
+    """Create the frozen prior model from its top layers, up to `last_layer` (reference cgan.py:21-30).
+
+    The reference reads a Keras .h5; here `prior_path` is the .npz layer list written by
+    `models.prior.save_prior` (same layer indexing: `model.layers[last_layer].output`).
+    The returned model is not trainable."""
+    from .models.prior import PriorNet, load_prior_layers
+    return PriorNet(load_prior_layers(prior_path), last_layer)
+
+
 class EM2EM(object):
     """Creates CGAN model for 1-channel 2d or 3d data and provides functions to train and predict.
 

@@ -337,6 +337,66 @@ int fill_dev(const tem_conv_args *a, ConvDev &p, bool transposed) {
     return TEM_OK;                                                                            \
   }
 
+// ------------------------------------------------------------------ any channel count
+// One thread per (output voxel, output channel), every extent a runtime value.  Not a fast path:
+// it exists so that geometries outside the hot path's channel table (a frozen prior network fed to
+// the discriminator, discriminator.py:62-66) run on the device instead of being refused.
+__global__ __launch_bounds__(256) void conv_generic_k(ConvDev p, int CI0, int CI1, int CO0, int CO1, int flip,
+                                                      int transposed) {
+  const int CI = CI0 + CI1, CO = CO0 + CO1;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total * CO) return;
+  const int co = (int)(idx % CO); int64_t r = idx / CO;
+  int x = (int)(r % p.OW); r /= p.OW;
+  int y = (int)(r % p.OH); r /= p.OH;
+  int z = (int)(r % p.OD); int n = (int)(r / p.OD);
+  const int ntap = p.kd * p.kh * p.kw;
+  float acc = 0.f;
+  for (int dz = 0; dz < p.kd; ++dz)
+    for (int dy = 0; dy < p.kh; ++dy)
+      for (int dx = 0; dx < p.kw; ++dx) {
+        int iz, iy, ix;
+        bool ok;
+        if (!transposed) {
+          iz = z * p.sd + dz - p.pd; iy = y * p.sh + dy - p.ph; ix = x * p.sw + dx - p.pw;
+          ok = iz >= 0 && iz < p.D && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        } else {                                          // out[o] += in[j] * w[t] for o = j*s + t - p
+          int tz = z + p.pd - dz, ty = y + p.ph - dy, tx = x + p.pw - dx;
+          ok = tz >= 0 && ty >= 0 && tx >= 0 && tz % p.sd == 0 && ty % p.sh == 0 && tx % p.sw == 0;
+          iz = tz / p.sd; iy = ty / p.sh; ix = tx / p.sw;
+          ok = ok && iz < p.D && iy < p.H && ix < p.W;
+        }
+        if (!ok) continue;
+        const int tap = (dz * p.kh + dy) * p.kw + dx;
+        const float *wt = p.w + (int64_t)((flip && !transposed) ? ntap - 1 - tap : tap) * (CI * CO);
+        const bool coci = flip || transposed;
+        const float *x0 = p.in0 + n * p.i0N + iz * p.i0D + iy * p.i0H + ix * p.i0W;
+        for (int ci = 0; ci < CI0; ++ci) acc = fmaf(x0[ci], coci ? wt[co * CI + ci] : wt[ci * CO + co], acc);
+        if (CI1 > 0) {
+          const float *x1 = p.in1 + n * p.i1N + iz * p.i1D + iy * p.i1H + ix * p.i1W;
+          for (int ci = 0; ci < CI1; ++ci)
+            acc = fmaf(x1[ci], coci ? wt[co * CI + CI0 + ci] : wt[(CI0 + ci) * CO + co], acc);
+        }
+      }
+  if (co < CO0) {
+    float v[1] = {acc};
+    apply_epilogue<1>(p.ep, v, n, z, y, x, co, p.OD, p.OH, p.OW, CO0);
+    p.out0[n * p.o0N + z * p.o0D + y * p.o0H + x * p.o0W + co] = v[0];
+  } else {
+    p.out1[n * p.o1N + z * p.o1D + y * p.o1H + x * p.o1W + (co - CO0)] = acc;
+  }
+}
+
+static int launch_generic(const ConvDev &p, const tem_conv_args *a, hipStream_t st, bool transposed) {
+  const int CI1 = a->in1.ptr ? a->in1.C : 0, CO1 = a->out1.ptr ? a->out1.C : 0;
+  const int64_t cnt = p.total * (a->out0.C + CO1);
+  if (cnt <= 0 || cnt > 0x7fffffffll * 256) return TEM_EUNSUPPORTED;
+  hipLaunchKernelGGL(conv_generic_k, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, p, a->in0.C, CI1, a->out0.C, CO1,
+                     a->w_layout == TEM_W_FLIP_CO_CI ? 1 : 0, transposed ? 1 : 0);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
 // row-blocked kernel: the full-resolution 8-channel / 1-channel layers of both networks
 #define ROWS_CASE(ci0, co0, fl, kh_, sh_, ny_)                                                            \
   if (CI0 == ci0 && CI1 == 0 && CO0 == co0 && CO1 == 0 && flip == fl && a->kh == kh_ && a->sh == sh_) {  \
@@ -368,7 +428,13 @@ static int conv_direct_impl(const tem_conv_args *a, hipStream_t st, char *name, 
     }
   }
   if (name) {
-    snprintf(name, name_len, "conv_direct_k<%d, %d, %d, %d, %s>", CI0, CI1, CO0, CO1, flip ? "true" : "false");
+    static const int table[][4] = {{1, 0, 8, 0}, {1, 0, 16, 0}, {1, 0, 32, 0}, {8, 0, 8, 0}, {8, 0, 16, 0}, {8, 0, 1, 0},
+                                   {16, 0, 16, 0}, {16, 0, 32, 0}, {16, 0, 8, 0}, {16, 0, 1, 0}, {32, 0, 32, 0}, {32, 0, 16, 0},
+                                   {32, 0, 1, 0}, {8, 8, 16, 0}, {16, 16, 32, 0}, {16, 0, 8, 8}, {32, 0, 16, 16}};
+    bool hit = false;
+    for (auto &t : table) hit = hit || (t[0] == CI0 && t[1] == CI1 && t[2] == CO0 && t[3] == CO1);
+    if (hit) snprintf(name, name_len, "conv_direct_k<%d, %d, %d, %d, %s>", CI0, CI1, CO0, CO1, flip ? "true" : "false");
+    else snprintf(name, name_len, "conv_generic_k");
     return TEM_OK;
   }
   // forward shapes
@@ -379,7 +445,7 @@ static int conv_direct_impl(const tem_conv_args *a, hipStream_t st, char *name, 
   CONV_CASE(8, 8, 16, 0) CONV_CASE(16, 16, 32, 0)
   // split outputs (input-gradient through a concat)
   CONV_CASE(16, 0, 8, 8) CONV_CASE(32, 0, 16, 16)
-  return TEM_EUNSUPPORTED;
+  return launch_generic(p, a, st, false);
 }
 
 extern "C" int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream) {
@@ -404,14 +470,14 @@ extern "C" int tem_conv_transpose_direct(const tem_conv_args *a, tem_stream_t st
   ConvDev p{};
   int rc = fill_dev(a, p, true);
   if (rc) return rc;
-  if (a->in1.ptr) return TEM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->in1.ptr) return launch_generic(p, a, st, true);
   const int CI0 = a->in0.C;
   const int CO0 = a->out0.C, CO1 = a->out1.ptr ? a->out1.C : 0;
-  hipStream_t st = (hipStream_t)stream;
   int ncls = a->sd * a->sh * a->sw;
   int64_t qmax = (int64_t)p.N * ((p.OD + a->sd - 1) / a->sd) * ((p.OH + a->sh - 1) / a->sh) * ((p.OW + a->sw - 1) / a->sw);
   dim3 grid((unsigned)((qmax + 255) / 256), (unsigned)ncls);
   CONVT_CASE(32, 16, 0, 16) CONVT_CASE(16, 8, 0, 8)                           // Conv3DTranspose forward
   CONVT_CASE(8, 8, 0, 8) CONVT_CASE(16, 16, 0, 16) CONVT_CASE(32, 32, 0, 8)   // input-grad of the k4 s2 convs
-  return TEM_EUNSUPPORTED;
+  return launch_generic(p, a, st, true);
 }

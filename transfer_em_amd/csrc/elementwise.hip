@@ -142,6 +142,16 @@ __global__ __launch_bounds__(256) void copy_view_k(V5 s, V5 d, int64_t total) {
   }
 }
 
+// g(view) = saved > 0 ? g : slope * g  (LeakyReLU gradient gated on the saved OUTPUT, in place)
+__global__ __launch_bounds__(256) void leaky_gate_view_k(V5 g, V5 sv, float slope, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int c;
+    int64_t go = voff(g, i, c), so = voff(sv, i, c);
+    float v = g.ptr[go];
+    g.ptr[go] = sv.ptr[so] > 0.f ? v : slope * v;
+  }
+}
+
 inline unsigned grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -249,6 +259,17 @@ extern "C" int tem_add_view(const tem_view *src, const tem_view *dst, tem_stream
   if (!same_extents(*src, *dst)) return TEM_ESHAPE;
   int64_t total = vtotal(*src);
   hipLaunchKernelGGL(copy_view_k<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dv(*src), dv(*dst),
+                     total);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+extern "C" int tem_leaky_gate_view(const tem_view *g, const tem_view *saved, float slope, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!g || !saved || !tem_view_ok(*g) || !tem_view_ok(*saved)) return TEM_EINVAL;
+  if (!same_extents(*g, *saved)) return TEM_ESHAPE;
+  int64_t total = vtotal(*g);
+  hipLaunchKernelGGL(leaky_gate_view_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dv(*g), dv(*saved), slope,
                      total);
   TEM_CHECK_LAUNCH();
   return TEM_OK;

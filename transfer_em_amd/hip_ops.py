@@ -322,6 +322,13 @@ def copy_view_launch(name, src, dst, add=False):
     return Launch(fn, (C.byref(vs), C.byref(vd)), name, [src, dst, vs, vd])
 
 
+def leaky_gate_launch(name, g, saved, slope):
+    """g = saved > 0 ? g : slope * g, in place."""
+    lib = _lib.load()
+    vg, vs = view(g), view(saved)
+    return Launch(lib.tem_leaky_gate_view, (C.byref(vg), C.byref(vs), float(slope)), name, [g, saved, vg, vs])
+
+
 def u8_to_f32_std(src_u8, dst_f32, mean, std, stream=None):
     lib = _lib.load()
     assert src_u8.dtype == torch.uint8 and src_u8.is_contiguous() and dst_f32.is_contiguous()

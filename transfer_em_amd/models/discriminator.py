@@ -12,13 +12,17 @@ import torch
 
 from .. import hip_ops as H
 from .params import ParamSet
+from .prior import PriorBackward, PriorForward
 
 DOUBLE_LEAKY = float(torch.tensor(0.3, dtype=torch.float32) * torch.tensor(0.3, dtype=torch.float32))
 
 
-def discriminator_param_shapes(is3d=True, wf=8):
+def discriminator_param_shapes(is3d=True, wf=8, prior_channels=0):
     if wf != 8:
         raise RuntimeError("the reference discriminator graph is only shape-consistent for wf == 8")
+    if prior_channels not in (0, 32):
+        # discriminator.py:62-66: Downsample_3 is built for dims = 64 = 32 + the prior's channels
+        raise RuntimeError("disc_prior must output 32 channels (Downsample_3 expects 64 input channels)")
     k3 = (3, 3, 3) if is3d else (1, 3, 3)
     k4 = (4, 4, 4) if is3d else (1, 4, 4)
     k1 = (1, 1, 1)
@@ -31,7 +35,7 @@ def discriminator_param_shapes(is3d=True, wf=8):
         s["hack"] = k3 + (1, 16)                      # discriminator.py:49-51 (raw input)
     s["d2a"] = k3 + (128 // wf, 256 // wf)            # Downsample_2
     s["d2b"] = k4 + (256 // wf, 256 // wf)
-    s["d3a"] = k3 + (32, 32)                          # Downsample_3 (dims=32 hard-coded, :60,72)
+    s["d3a"] = k3 + (32 + prior_channels, 32)         # Downsample_3 (dims=32 hard-coded, :60,72; 64 with a prior, :66)
     s["d3b"] = k4 + (32, 32)
     s["p1"] = k1 + (32, 256 // wf)                    # discriminator.py:78-80
     s["p2"] = k1 + (256 // wf, 1)                     # discriminator.py:97-99 (with bias)
@@ -74,6 +78,7 @@ class DiscForward:
         A = self.act = {}
         L = self.launches = []
         prev = x
+        self.prior_fwd = None
         for name in self.order:
             n = e[name]
             if n < 1:
@@ -81,9 +86,19 @@ class DiscForward:
             A[name] = torch.empty((N, n if is3d else 1, n, n, P.shapes[name][-1]), dtype=torch.float32,
                                   device=x.device)
             k, s = _GEOM[name]
+            in1 = None
+            if name == "d3a" and net.prior is not None:
+                # x2 = disc_prior(inp); x = Concatenate()([x, x2])  (discriminator.py:62-66): the concat is
+                # a second input view of the consuming convolution, never materialised
+                self.prior_fwd = PriorForward(net.prior, x)
+                in1 = self.prior_fwd.y
+                if tuple(in1.shape[:4]) != tuple(prev.shape[:4]):
+                    raise RuntimeError(f"disc_prior output {tuple(in1.shape)} does not match Downsample_2's "
+                                       f"output {tuple(prev.shape)}")
+                L.extend(self.prior_fwd.launches)
             L.append(H.conv_launch("d." + name, prev, P.w(name), A[name], k, s, 0, is3d=is3d if k > 1 else True,
-                                   slope=_SLOPE.get(name, H.LEAKY), bias=P.w("p2_bias") if name == "p2" else None,
-                                   direct=direct))
+                                   in1=in1, slope=_SLOPE.get(name, H.LEAKY),
+                                   bias=P.w("p2_bias") if name == "p2" else None, direct=direct))
             prev = A[name]
         self.z = A["p2"]
 
@@ -105,13 +120,17 @@ class DiscBackward:
         self.dx = torch.empty_like(fwd.x) if need_dx else None
         L = self.launches = []
         g_out = dz
+        pf = fwd.prior_fwd
+        g_feat = torch.empty_like(pf.y) if pf is not None else None
         for i in range(len(order) - 1, -1, -1):
             name = order[i]
             k, s = _GEOM[name]
             i3 = is3d if k > 1 else True
             xin = A[order[i - 1]] if i > 0 else fwd.x
+            with_prior = name == "d3a" and pf is not None
             if need_dw:
-                L.append(H.bww_launch("d.bww." + name, xin, g_out, ws, name, call, k, s, 0, is3d=i3))
+                L.append(H.bww_launch("d.bww." + name, xin, g_out, ws, name, call, k, s, 0, is3d=i3,
+                                      in1=pf.y if with_prior else None))
                 if name == "p2":
                     L.append(H.bias_grad_launch("d.bias", g_out, ws, "p2_bias", call))
             if i == 0 and not need_dx:
@@ -120,12 +139,20 @@ class DiscBackward:
             gate = A[order[i - 1]] if i > 0 else None
             gslope = _SLOPE.get(order[i - 1], H.LEAKY) if i > 0 else 1.0
             if s == 1:
+                # with a prior the gradient of the concat splits: channels 0..31 to the trunk (gated by
+                # Downsample_2's LeakyReLU), the rest, ungated, to the prior's output
                 L.append(H.conv_launch("d.bd." + name, g_out, P.w(name), dst, k, 1, k - 1, is3d=i3,
+                                       out1=g_feat if with_prior else None,
                                        layout=H.TEM_W_FLIP_CO_CI, gate=gate, gate_slope=gslope, direct=direct))
             else:
                 L.append(H.conv_launch("d.bd." + name, g_out, P.w(name), dst, k, s, 0, is3d=i3, transposed=True,
                                        gate=gate, gate_slope=gslope, direct=direct))
             g_out = dst
+        self.prior_bwd = None
+        if pf is not None and need_dx:       # the prior is frozen but differentiable w.r.t. the image
+            self.prior_bwd = PriorBackward(pf, g_feat, self.dx)
+            L.extend(self.prior_bwd.launches)
+        self._keep = (g_feat,)
 
     def run(self, stream=None):
         H.run(self.launches, stream)
@@ -134,12 +161,11 @@ class DiscBackward:
 class Discriminator:
     def __init__(self, is3d=True, norm_type="instancenorm", wf=8, disc_prior=None, device=None, seed=None):
         H.require_gpu()
-        if disc_prior is not None:
-            raise NotImplementedError("disc_prior (frozen prior-net features, discriminator.py:62-66) is not "
-                                      "built yet -- SURVEY 8(f) row 4")
         self.is3d, self.wf, self.norm_type = is3d, wf, norm_type
         self.device = torch.device(device or "cuda")
-        self.params = ParamSet(discriminator_param_shapes(is3d, wf), self.device, seed)
+        self.prior = disc_prior                      # models.prior.PriorNet (frozen) or None
+        pc = disc_prior.out_channels if disc_prior is not None else 0
+        self.params = ParamSet(discriminator_param_shapes(is3d, wf, pc), self.device, seed)
         self._plans = {}
 
     @property
