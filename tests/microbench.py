@@ -16,7 +16,7 @@ rnd = lambda *s: torch.randn(*s, device=dev, dtype=torch.float32)
 # name: (CI, CO, k, s, in_edge)
 GEOM = dict(f1=(16, 16, 3, 1, 100), mid=(32, 32, 3, 1, 54), d1a=(8, 8, 3, 1, 130), u1a=(32, 16, 3, 1, 52),
             d1b=(8, 8, 4, 2, 128), f2=(16, 1, 3, 1, 98), c0=(1, 8, 3, 1, 132), d2a=(8, 16, 3, 1, 64),
-            D2b=(32, 32, 4, 2, 42), g2b=(16, 16, 4, 2, 62), u2b=(32, 16, 4, 2, 26), u1b=(16, 8, 4, 2, 50))
+            x816=(8, 16, 3, 1, 130), x1616=(16, 16, 3, 1, 130), D2b=(32, 32, 4, 2, 42), g2b=(16, 16, 4, 2, 62), u2b=(32, 16, 4, 2, 26), u1b=(16, 8, 4, 2, 50))
 
 
 class _P:

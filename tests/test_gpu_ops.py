@@ -161,7 +161,9 @@ def test_input_gradient_split_through_concat(H, oracle_lib):
 
 BWW_CASES = [(1, 8, 3, 1, 0, 14), (8, 8, 3, 1, 0, 12), (8, 8, 4, 2, 0, 14), (8, 16, 3, 1, 0, 10), (16, 16, 4, 2, 0, 11),
              (16, 32, 3, 1, 0, 8), (32, 32, 3, 1, 0, 8), (32, 16, 3, 1, 0, 8), (16, 1, 3, 1, 0, 10), (32, 32, 4, 2, 0, 10),
-             (32, 32, 1, 1, 0, 6), (32, 1, 1, 1, 0, 6), (1, 8, 3, 1, 4, 8)]
+             (32, 32, 1, 1, 0, 6), (32, 1, 1, 1, 0, 6), (1, 8, 3, 1, 4, 8),
+             # C_out = 8 x-shift form: output width a multiple of 8 (needs the extra padded voxel), zero padding
+             (8, 8, 4, 2, 0, 33), (8, 8, 3, 1, 2, 9), (8, 8, 3, 1, 0, 17)]
 
 
 class _P:          # minimal stand-in for a ParamSet: one layer "w"

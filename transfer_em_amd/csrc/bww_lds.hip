@@ -16,9 +16,16 @@
 // every input byte is read ~(R+K-S)/R times per workgroup column instead of K^3 times.
 // Both MFMA fragments are plain ds_read_b32: A = [4 voxels][16 (tap,ci) rows], B = [4 voxels]
 // [16 co] -- the channels-last layout as it is.
+//
+// C_out == 8 (XSH): an 8-wide gradient would leave half of every 16-column MFMA tile empty.  Columns
+// 8..15 are fed the SAME gradient shifted by one output voxel in x,
+//   D[(tz,ty,tx,ci)][8 + co] = sum_v X[v*S + tx][ci] * G[v - 1][co] = dW[(tz,ty,tx + S,ci)][co],
+// so a tile row delivers two x-taps at once and only the x-taps tx < K - S need rows of their own:
+// 9 instead of 14 tiles for k3 s1 (8 -> 8), 16 instead of 32 for k4 s2.
 #include "tem_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace bwwlds {
 
@@ -42,11 +49,13 @@ struct Dev {
 };
 
 
-template <int CI, int CO, int K, int S, int NW>
+template <int CI, int CO, int K, int S, int NW, bool XSH = false>
 struct Cfg {
+  static_assert(!XSH || CO == 8, "the x-shift form pairs two 8-channel gradients in one n-tile");
   static constexpr int CIP = CI == 1 ? 1 : CI + 2;
   static constexpr int COP = CO + 2;
-  static constexpr int ROWS = K * K * K * CI;
+  static constexpr int KXR = XSH ? K - S : K;           // x-taps that own tile rows
+  static constexpr int ROWS = K * K * KXR * CI;
   static constexpr int MTILES = (ROWS + 15) / 16;
   static constexpr int NT = (CO + 15) / 16;
   static constexpr int T = MTILES * NT;
@@ -57,6 +66,9 @@ struct Cfg {
   static constexpr int TPW = (T + WG - 1) / WG;
   static constexpr int CHX = CI % 4 == 0 ? 4 : 1;     // floats per loader chunk
   static constexpr int CHG = CO % 4 == 0 ? 4 : 1;
+  // one tile more than waves (k3 s1 x-shift form: 9 tiles, 8 waves): every wave owns one tile, the last tile
+  // is summed by wave r for output row r and reduced across the waves at the end
+  static constexpr bool SHR = XSH && KSPL == 1 && T == WG + 1;
   static_assert(NW % NT == 0 && WG % NT == 0 && NW % KSPL == 0, "a wave keeps one n-tile");
 };
 
@@ -86,16 +98,16 @@ __device__ __forceinline__ void lstore(float *p, const Chunk<CH> &c) {
 }
 
 // PFX / PFG: register-staged loader chunks per thread per z-step (X planes / gradient rows)
-template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MAXPFG>
+template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MAXPFG, bool XSH = false>
 __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
-  using C = Cfg<CI, CO, K, S, NW>;
+  using C = Cfg<CI, CO, K, S, NW, XSH>;
   constexpr int CIP = C::CIP, COP = C::COP, NT = C::NT, TPW = C::TPW, CHX = C::CHX, CHG = C::CHG;
   constexpr int NTHR = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rowpitch = p.WXp * CIP;
   const int slotpitch = p.YR * rowpitch;
   float *Xs = lds;
-  float *Gs = lds + K * slotpitch;
+  float *Gs = lds + K * slotpitch + (XSH ? COP : 0);     // XSH: one zero voxel in front of row 0 (G[-1])
   const int growpitch = p.OWp * COP;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
 
   // ---- zero the whole LDS image once (slack voxels and never-written rows must stay finite)
   {
-    const int total4 = (K * slotpitch + p.R * growpitch + 3) / 4;      // allocation is rounded up to 16 B
+    const int total4 = (K * slotpitch + p.R * growpitch + (XSH ? COP : 0) + 3) / 4;      // allocation is rounded up to 16 B
     for (int i = tid; i < total4; i += NTHR) reinterpret_cast<float4 *>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
@@ -204,13 +216,14 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
     int mt = t / NT;
     int row = min(mt * 16 + m, C::ROWS - 1);              // rows >= ROWS are never stored
     int tap = row / CI, ci = row - tap * CI;
-    int dx = tap % K, dy = (tap / K) % K;
-    adz[j] = tap / (K * K);
+    int dx = tap % C::KXR, dy = (tap / C::KXR) % K;
+    adz[j] = tap / (C::KXR * K);
     aconst[j] = dy * rowpitch + dx * CIP + ci + kq * S * CIP;
     acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool bvalid = (nt * 16 + m) < CO;
-  const int boff = kq * COP + nt * 16 + (bvalid ? m : 0);
+  const bool bvalid = XSH || (nt * 16 + m) < CO;
+  // XSH: columns 8..15 read the gradient one voxel to the left (zero in front of x = 0)
+  const int boff = XSH ? (kq - (m >> 3)) * COP + (m & 7) : kq * COP + nt * 16 + (bvalid ? m : 0);
 
   Chunk<CHX> pfx[MAXPFX];
   Chunk<CHG> pfg[MAXPFG];
@@ -252,35 +265,44 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
     // the next k-step are issued BEFORE the current k-step's MFMAs (sched_barrier pins that order),
     // so their latency hides under TPW back-to-back MFMAs.  OWp is a multiple of 8: nk is even.
     const int nk = p.OWp >> 2;
-    for (int r = kshare; r < p.R; r += KSPL) {
+    auto row_pass = [&](auto ntl_tag, int r) {             // NTL = accumulator tiles this wave feeds on row r
+      constexpr int NTL = decltype(ntl_tag)::value;
       const float *xr = Xs + r * S * rowpitch;
       const float *gr = Gs + r * growpitch + boff;
-      float a0[TPW], a1[TPW], b0, b1;
+      float a0[NTL], a1[NTL], b0, b1;
       b0 = gr[0];
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) a0[j] = xr[abase[j]];
+      for (int j = 0; j < NTL; ++j) a0[j] = xr[abase[j]];
       for (int k = 0; k < nk; k += 2) {
         b1 = gr[(k + 1) * 4 * COP];
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) a1[j] = xr[abase[j] + (k + 1) * 4 * S * CIP];
+        for (int j = 0; j < NTL; ++j) a1[j] = xr[abase[j] + (k + 1) * 4 * S * CIP];
         __builtin_amdgcn_sched_barrier(0);
         {
           const float b = bvalid ? b0 : 0.f;
 #pragma unroll
-          for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b, acc[j], 0, 0, 0);
+          for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b, acc[j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         const int k2 = k + 2 < nk ? k + 2 : k;             // past the end: re-read, never used
         b0 = gr[k2 * 4 * COP];
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) a0[j] = xr[abase[j] + k2 * 4 * S * CIP];
+        for (int j = 0; j < NTL; ++j) a0[j] = xr[abase[j] + k2 * 4 * S * CIP];
         __builtin_amdgcn_sched_barrier(0);
         {
           const float b = bvalid ? b1 : 0.f;
 #pragma unroll
-          for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b, acc[j], 0, 0, 0);
+          for (int j = 0; j < NTL; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b, acc[j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int r = kshare; r < p.R; r += KSPL) {
+      if constexpr (C::SHR) {
+        if ((r % NW) == wave) row_pass(std::integral_constant<int, 2>{}, r);    // wave-uniform
+        else row_pass(std::integral_constant<int, 1>{}, r);
+      } else {
+        row_pass(std::integral_constant<int, TPW>{}, r);
       }
     }
     __syncthreads();                                       // everyone is done with the oldest planes / G rows
@@ -310,6 +332,20 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
         }
     }
   }
+  if constexpr (C::SHR) {                                  // the shared last tile: sum the waves' row shares
+    float *red = lds;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[(wave * 4 + q) * 64 + lane] = acc[1][q];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = 0.f;
+        for (int w = 0; w < NW; ++w) v += red[(w * 4 + q) * 64 + lane];
+        acc[1][q] = v;
+      }
+    }
+  }
   float *slab = p.slabs + (int64_t)blockIdx.x * p.slab_stride;
   if (kshare == 0) {
 #pragma unroll
@@ -321,7 +357,16 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           int row = mt * 16 + kq * 4 + q;                  // C/D map: row = 4*(lane>>4)+reg, col = lane&15
-          if (row < C::ROWS && co < CO) slab[(int64_t)row * CO + co] = acc[j][q];
+          if constexpr (XSH) {
+            // row = ((tz*K + ty)*KXR + txr)*CI + ci; column m = shift*8 + co  ->  tap tx = txr + shift*S
+            const int tap = row / CI, ci = row - tap * CI;
+            const int txr = tap % C::KXR, tzy = tap / C::KXR, sh = m >> 3;
+            const int tx = txr + sh * S;
+            const bool dup = sh == 0 && txr >= S;           // also delivered as (txr - S, shifted): keep that one
+            if (row < C::ROWS && !dup) slab[((int64_t)(tzy * K + tx) * CI + ci) * CO + (m & 7)] = acc[j][q];
+          } else {
+            if (row < C::ROWS && co < CO) slab[(int64_t)row * CO + co] = acc[j][q];
+          }
         }
       }
     }
@@ -337,12 +382,12 @@ constexpr int TARGET_BLOCKS = 512;
 static uint32_t magic_for(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
 
 // Fills the plan fields of `p`; returns false when the geometry does not fit this kernel.
-template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MAXPFG>
+template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MAXPFG, bool XSH>
 bool plan(Dev &p, int max_slabs, size_t &lds_bytes, int &nblocks) {
-  using C = Cfg<CI, CO, K, S, NW>;
+  using C = Cfg<CI, CO, K, S, NW, XSH>;
   const int NTHR = NW * 64;
   p.WX = (p.OW - 1) * S + K;
-  p.OWp = (p.OW + 7) & ~7;                 // even number of 4-voxel k-steps
+  p.OWp = (p.OW + (XSH ? 1 : 0) + 7) & ~7; // even number of 4-voxel k-steps (XSH: one more voxel for the shifted columns)
   p.WXp = p.WX + (p.OWp - p.OW) * S + 1;   // slack voxels the padded k-steps read (kept zero)
   p.chunksX = C::CHX == 4 ? p.WX * (CI / 4) : p.WX;
   p.chunksG = C::CHG == 4 ? p.OW * (CO / 4) : p.OW;
@@ -351,12 +396,12 @@ bool plan(Dev &p, int max_slabs, size_t &lds_bytes, int &nblocks) {
   int R = p.OH < 8 ? p.OH : 8;
   for (; R >= 1; --R) {
     int YR = (R - 1) * S + K;
-    size_t bytes = ((size_t)K * YR * p.WXp * C::CIP + (size_t)R * p.OWp * C::COP) * 4;
+    size_t bytes = ((size_t)K * YR * p.WXp * C::CIP + (size_t)R * p.OWp * C::COP + (XSH ? C::COP : 0)) * 4;
     bool fits = bytes <= (size_t)LDS_BUDGET && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * NTHR &&
                 (size_t)R * p.chunksG <= (size_t)MAXPFG * NTHR;
     if (fits) {
       p.R = R; p.YR = YR;
-      size_t red = C::KSPL > 1 ? (size_t)NW * C::TPW * 4 * 64 * 4 : 0;   // the row-share reduction reuses the ring
+      size_t red = (C::KSPL > 1 || C::SHR) ? (size_t)NW * C::TPW * 4 * 64 * 4 : 0;   // the row-share reduction reuses the ring
       lds_bytes = ((bytes > red ? bytes : red) + 15) & ~(size_t)15;
       break;
     }
@@ -376,17 +421,19 @@ bool plan(Dev &p, int max_slabs, size_t &lds_bytes, int &nblocks) {
   return nblocks <= max_slabs;
 }
 
-template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MAXPFG>
+template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MAXPFG, bool XSH = false>
 int run(Dev &p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   size_t lds_bytes = 0;
   int nblocks = 0;
-  if (!plan<CI, CO, K, S, NW, MAXPFX, MAXPFG>(p, max_slabs, lds_bytes, nblocks)) return TEM_EUNSUPPORTED;
+  if (!plan<CI, CO, K, S, NW, MAXPFX, MAXPFG, XSH>(p, max_slabs, lds_bytes, nblocks)) return TEM_EUNSUPPORTED;
   if (nslab_out) *nslab_out = nblocks;
   if (dry) {
-    if (g_name) snprintf(g_name, g_name_len, "bww_lds_k<%d, %d, %d, %d, %d, %d, %d>", CI, CO, K, S, NW, MAXPFX, MAXPFG);
+    if (g_name)
+      snprintf(g_name, g_name_len, XSH ? "bww_lds_k<%d, %d, %d, %d, %d, %d, %d, true>" : "bww_lds_k<%d, %d, %d, %d, %d, %d, %d>", CI,
+               CO, K, S, NW, MAXPFX, MAXPFG);
     return TEM_OK;
   }
-  auto kern = bww_lds_k<CI, CO, K, S, NW, MAXPFX, MAXPFG>;
+  auto kern = bww_lds_k<CI, CO, K, S, NW, MAXPFX, MAXPFG, XSH>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -400,6 +447,8 @@ int run(Dev &p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
 
 #define BWW_CASE(ci, co, k, s, nw, pfx, pfg) \
   if (CI == ci && CO == co && K == k && S == s) return run<ci, co, k, s, nw, pfx, pfg>(p, max_slabs, st, dry, nslab_out);
+#define BWW_CASE_XSH(ci, co, k, s, nw, pfx, pfg) \
+  if (CI == ci && CO == co && K == k && S == s && xsh) return run<ci, co, k, s, nw, pfx, pfg, true>(p, max_slabs, st, dry, nslab_out);
 
 // Dispatch; `dry` only computes the number of slabs the launch would write.
 int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
@@ -432,6 +481,10 @@ int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
   };
   if (!aligned(i0) || (a->in1.ptr && !aligned(a->in1)) || !aligned(g)) return TEM_EUNSUPPORTED;
   //        CI  CO  K  S  waves  X-chunks  G-chunks     (tiles per wave = ceil(K^3*CI/16 * ceil(CO/16) / waves))
+  static int xsh = -1;
+  if (xsh < 0) { const char *v = getenv("TEM_BWW_XSH"); xsh = v ? atoi(v) : 1; }
+  BWW_CASE_XSH(8, 8, 3, 1, 8, 4, 3)  // g.d1a: 9 tiles in the x-shift form
+  BWW_CASE_XSH(8, 8, 4, 2, 8, 6, 2)  // g.d1b / d.d1b: 16 tiles
   BWW_CASE(1, 8, 3, 1, 8, 3, 4)      // g.c0 / d.d1a: 2 tiles x 4 row shares, HBM-bound on the gradient stream
   BWW_CASE(8, 8, 3, 1, 8, 4, 3)      // g.d1a: 14 tiles
   BWW_CASE(8, 16, 3, 1, 8, 4, 3)     // g.d2a / d.hack
