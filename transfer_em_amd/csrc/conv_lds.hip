@@ -30,6 +30,11 @@
 
 namespace convlds {
 
+// Steady-state loader: true = every wave fetches its share of the next planes (the chunk count per thread and
+// the descriptor registers halve); false = only the upper half of the waves loads.
+constexpr bool LOADER_ALL = true;
+constexpr int pfx_of(int half_loader_chunks) { return LOADER_ALL ? (half_loader_chunks + 1) / 2 : half_loader_chunks; }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Ep32 {                    // epilogue with 32-bit strides
@@ -276,12 +281,14 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   // step, taken from in1) -- so that a step's loader is ~4 VALU per 16-byte chunk.
   int goff[MAXPFX], loff[MAXPFX];
   uint32_t okmask = 0, plmask = 0, srcmask = 0;
+  constexpr int LTHR = LOADER_ALL ? NTHR : NTHR / 2;      // threads that run the steady-state loader
+  const bool loads = LOADER_ALL || late;
   {
-    const int ltid = tid - NTHR / 2, total = S * p.YR * p.chunksX;
+    const int ltid = LOADER_ALL ? tid : tid - NTHR / 2, total = S * p.YR * p.chunksX;
 #pragma unroll
     for (int i = 0; i < MAXPFX; ++i) {
-      int id = ltid + i * (NTHR / 2);
-      bool ok = late && id < total;
+      int id = ltid + i * LTHR;
+      bool ok = loads && id < total;
       int rowid = __umulhi((uint32_t)(ok ? id : 0), p.magicX);
       int pos = (ok ? id : 0) - rowid * p.chunksX;
       int pl = rowid >= p.YR ? 1 : 0;
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
     const bool more = step + 1 < nsteps;
     // Only the late half fetches the next planes: the early half goes straight to its MFMA stream, so the
     // matrix pipe is busy while the loader's address arithmetic and load issue run on the partner waves.
-    if (late && more && !(p.dbg & 4)) load_fast(pfx, izb + K);
+    if (loads && more && !(p.dbg & 4)) load_fast(pfx, izb + K);
 
     STAMP(1);                                              // load_x issue
     if (late && step > 0) epilogue(acc_prev, oz - 1);
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
     STAMP(4);                                              // epilogue (early half) / acc copy
     __syncthreads();                                       // all waves are done reading the oldest planes
     STAMP(5);                                              // barrier 1 wait
-    if (late && more && !(p.dbg & 4)) store_fast(pfx, izb + K);
+    if (loads && more && !(p.dbg & 4)) store_fast(pfx, izb + K);
     STAMP(6);                                              // store_x
     __syncthreads();
     STAMP(7);                                              // barrier 2 wait
@@ -449,7 +456,7 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
     int ntiles = S == 1 ? (r * p.WP + 15) / 16 : r * p.nseg;
     // ring + tail the last tiles over-read + one 16 x 20 transpose patch per wave
     size_t bytes = ((size_t)K * YR * p.WP * CIP + (S == 1 ? 20 : 40) * CIP + 4 + NW * 16 * 20) * 4;
-    bool fits = bytes <= (size_t)LDS_MAX && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * (NTHR / 2) &&
+    bool fits = bytes <= (size_t)LDS_MAX && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * (LOADER_ALL ? NTHR : NTHR / 2) &&
                 ntiles * NT <= MTW * NW;
     if (!fits) continue;
     int rounds = (ntiles * NT + NW - 1) / NW;                      // tile slots each wave executes per step
@@ -508,9 +515,9 @@ int run_best(const Dev &p, hipStream_t st, bool dry) {
 }
 
 #define CONV_CASE(ci, co, k, s, nw, pfx, mtw) \
-  if (CI == ci && CO == co && K == k && S == s && !a->ep.dropout) return run_best<ci, co, k, s, nw, pfx, false>(p, st, dry);
+  if (CI == ci && CO == co && K == k && S == s && !a->ep.dropout) return run_best<ci, co, k, s, nw, pfx_of(pfx), false>(p, st, dry);
 #define CONV_CASE_DROP(ci, co, k, s, nw, pfx, mtw) \
-  if (CI == ci && CO == co && K == k && S == s && a->ep.dropout) return run_best<ci, co, k, s, nw, pfx, true>(p, st, dry);
+  if (CI == ci && CO == co && K == k && S == s && a->ep.dropout) return run_best<ci, co, k, s, nw, pfx_of(pfx), true>(p, st, dry);
 
 int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   const tem_view &i0 = a->in0, &o0 = a->out0;
