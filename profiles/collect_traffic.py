@@ -26,7 +26,7 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in fetch:
-        name = k.split("(")[0].replace("void ", "").split("::")[-1]
+        name = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").split("::")[-1]
         if "_k<" not in name:            # only this library's kernels
             continue
         out[name] = {"fetch_kib_raw": fetch[k], "write_kib": write.get(k, 0.0),

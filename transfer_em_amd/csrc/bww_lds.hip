@@ -429,8 +429,8 @@ int run(Dev &p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   if (nslab_out) *nslab_out = nblocks;
   if (dry) {
     if (g_name)
-      snprintf(g_name, g_name_len, XSH ? "bww_lds_k<%d, %d, %d, %d, %d, %d, %d, true>" : "bww_lds_k<%d, %d, %d, %d, %d, %d, %d>", CI,
-               CO, K, S, NW, MAXPFX, MAXPFG);
+      snprintf(g_name, g_name_len, "bww_lds_k<%d, %d, %d, %d, %d, %d, %d, %s>", CI, CO, K, S, NW, MAXPFX, MAXPFG,
+               XSH ? "true" : "false");
     return TEM_OK;
   }
   auto kern = bww_lds_k<CI, CO, K, S, NW, MAXPFX, MAXPFG, XSH>;
