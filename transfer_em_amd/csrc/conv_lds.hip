@@ -66,6 +66,7 @@ struct Dev {
   uint32_t magicX, magicWP, magicSeg;
   int32_t chunksX;
   unsigned long long *stamps;    // diagnostic: per-phase cycle sums [block][wave][8] (null in normal runs)
+  int32_t patch;                 // epilogue transpose: 1 = through a 16 x 20 LDS patch per wave, 0 = ds_bpermute (no LDS)
   int32_t dbg;                   // ablation switches (TEM_DEBUG_FLAGS env, perf triage only): 1 no stores, 2 no MFMA, 4 no prefetch
   Ep32 ep;
 };
@@ -74,7 +75,6 @@ template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MTW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   constexpr int CIP = CI + 2, NT = (CO + 15) / 16, KS = CI / 4, NTHR = NW * 64, NTAP = K * K * K;
   constexpr int TAIL = S == 1 ? 20 : 40;                  // voxels the last tiles over-read past the ring
-  constexpr int TPITCH = 20;                              // floats per row of the epilogue transpose tile
   static_assert(CI % 16 == 0 && NW % NT == 0, "C_in 16 or 32: an even number of k-step pairs per tap");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rowpitch = p.WP * CIP;
@@ -184,13 +184,18 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   };
 
   // ---- epilogue.  The MFMA leaves each lane with ONE channel of FOUR voxels (C/D map: col = lane&15,
-  // row = 4*(lane>>4)+reg).  Every wave transposes its 16x16 tile through a private 1.25 KB LDS patch
-  // so that a lane owns FOUR consecutive channels of ONE voxel: the gate / add loads and the stores
-  // become single 16-byte accesses (a full 64-byte channel run per voxel, 1 KB per wave-instruction),
-  // and the dropout bits of the four channels come from one Philox call.
+  // row = 4*(lane>>4)+reg).  Every wave transposes its 16x16 tile so that a lane owns FOUR consecutive
+  // channels of ONE voxel: the gate / add loads and the stores become single 16-byte accesses (a full
+  // 64-byte channel run per voxel, 1 KB per wave-instruction), and the dropout bits of the four channels
+  // come from one Philox call.  The transpose goes through a private 1.25 KB LDS patch per wave, or -- when
+  // those 10 KB are what keeps one more output row per workgroup out of the 160 KB (p.patch == 0, host's
+  // choice) -- through ds_bpermute (the LDS crossbar, no storage, ~900 cycles more per tile).
+  constexpr int TPITCH = 20;                              // floats per row of the transpose patch
   float *tp = lds + ((K * slotpitch + TAIL * CIP + 3) & ~3) + wave * (16 * TPITCH);   // 16-byte aligned
   const int ti = lane >> 2, tcq = lane & 3;               // transposed role: voxel row, channel quad
   const int tco = nt * 16 + tcq * 4;
+  const int tsrc = (16 * (ti >> 2) + 4 * tcq) * 4;        // byte address of the lane holding (row ti, channel 4*tcq)
+  const int tq = ti & 3;                                  // ... in accumulator register tq
   auto epilogue = [&](const f32x4 (&acc)[MTW], int oz) {
     const bool first = tco < p.CO0;
     const bool cvalid = tco < CO;
@@ -208,10 +213,24 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
       if (pr < npairs) {                                   // wave-uniform
         int t = pr / NT;
         asm volatile("" : "+s"(t));                        // per-step recompute: no hoisted per-tile registers
+        float4 v4;
+        if (p.patch) {                                     // kernel-uniform
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tp[(kq * 4 + q) * TPITCH + m] = acc[j][q];
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wave's own LDS writes have landed
-        const float4 v4 = *reinterpret_cast<const float4 *>(tp + ti * TPITCH + tcq * 4);
+          for (int q = 0; q < 4; ++q) tp[(kq * 4 + q) * TPITCH + m] = acc[j][q];
+          __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave's own LDS writes have landed
+          v4 = *reinterpret_cast<const float4 *>(tp + ti * TPITCH + tcq * 4);
+        } else {
+          float t4[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              r[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc + 4 * c, __float_as_int(acc[j][q])));
+            t4[c] = tq == 0 ? r[0] : (tq == 1 ? r[1] : (tq == 2 ? r[2] : r[3]));
+          }
+          v4 = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
         int r, ox;
         if (S == 1) {
           const int v = t * 16 + ti;
@@ -454,8 +473,9 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
   for (int r = 1; r <= (p.OH < 16 ? p.OH : 16); ++r) {
     int YR = (r - 1) * S + K;
     int ntiles = S == 1 ? (r * p.WP + 15) / 16 : r * p.nseg;
-    // ring + tail the last tiles over-read + one 16 x 20 transpose patch per wave
-    size_t bytes = ((size_t)K * YR * p.WP * CIP + (S == 1 ? 20 : 40) * CIP + 4 + NW * 16 * 20) * 4;
+   for (int patch = 1; patch >= 0; --patch) {
+    // ring + tail the last tiles over-read (+ one 16 x 20 transpose patch per wave)
+    size_t bytes = ((size_t)K * YR * p.WP * CIP + (S == 1 ? 20 : 40) * CIP + 4 + (patch ? NW * 16 * 20 : 0)) * 4;
     bool fits = bytes <= (size_t)LDS_MAX && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * (LOADER_ALL ? NTHR : NTHR / 2) &&
                 ntiles * NT <= MTW * NW;
     if (!fits) continue;
@@ -464,6 +484,7 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
     int cols = p.N * nych;
     if (rounds > MTW) continue;
     double step = 2.0 * MTW * NTAPS * KSTEPS * 32.0 * 1.35 + 2500.0 + 600.0 * MTW;   // every wave runs MTW slots
+    if (!patch) step += 900.0 * MTW;                  // measured: the ds_bpermute transpose costs ~900 cycles per tile
     double pro = 12000.0 + bytes / 12.0;              // first K planes arrive at the CU's HBM share (~12 B/clk)
     for (int zs = 1; zs <= p.OD; ++zs) {
       int zper = (p.OD + zs - 1) / zs, zsegs = (p.OD + zper - 1) / zper;
@@ -471,9 +492,10 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
       double t = std::ceil(cols * zsegs / 256.0) * (pro + zper * step);
       if (t < best) {
         best = t; R = r; p.R = r; p.YR = YR; p.ntiles = ntiles; lds_bytes = (bytes + 15) & ~(size_t)15;
-        p.nych = nych; p.zper = zper; p.zsegs = zsegs;
+        p.nych = nych; p.zper = zper; p.zsegs = zsegs; p.patch = patch;
       }
     }
+   }
   }
   if (R < 1) return TEM_EUNSUPPORTED;
   if (cost) *cost = best;
@@ -487,8 +509,8 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
     return TEM_OK;
   }
   if (p.dbg & 8)
-    fprintf(stderr, "conv_lds<%d,%d,%d,%d> OW=%d OH=%d OD=%d: R=%d YR=%d ntiles=%d nych=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI, CO, K, S,
-            p.OW, p.OH, p.OD, p.R, p.YR, p.ntiles, p.nych, p.zsegs, p.zper, nblocks, lds_bytes);
+    fprintf(stderr, "conv_lds<%d,%d,%d,%d> OW=%d OH=%d OD=%d: R=%d YR=%d ntiles=%d nych=%d zsegs=%d zper=%d blocks=%d lds=%zu patch=%d\n", CI, CO, K, S,
+            p.OW, p.OH, p.OD, p.R, p.YR, p.ntiles, p.nych, p.zsegs, p.zper, nblocks, lds_bytes, p.patch);
   auto kern = conv_lds_k<CI, CO, K, S, NW, MAXPFX, MTW, DROP>;
   static bool attr_set = false;
   if (!attr_set) {
