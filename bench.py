@@ -15,6 +15,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; must be set before HIP initialises
+
 import numpy as np
 import torch
 
