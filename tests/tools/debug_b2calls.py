@@ -1,5 +1,5 @@
 """Debug helper: per generator call, compare every gated input-gradient of the HIP backward with the oracle's."""
-import sys, os; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from test_gpu_step import _inputs, _state, _load
 from oracle import graph, ops

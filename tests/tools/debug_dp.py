@@ -1,5 +1,5 @@
 import os, sys, time, torch, torch.distributed as dist
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 dist.init_process_group(os.environ.get("TEM_DIST_BACKEND", "gloo"))
 rank = dist.get_rank()
 torch.cuda.set_device(0)

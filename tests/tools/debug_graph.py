@@ -1,5 +1,5 @@
 import sys, os, faulthandler; faulthandler.enable()
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from transfer_em_amd.cgan import EM2EM
 mode = sys.argv[1]

@@ -1,8 +1,8 @@
 """Debug helper (not a test): per-layer gradient errors of one train step vs the oracle."""
 import sys, os
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from util import rel_err, scaled_params
 from oracle import graph
 from transfer_em_amd.cgan import EM2EM

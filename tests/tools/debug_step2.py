@@ -1,8 +1,8 @@
 """Debug helper: isolate what changes generator kernel-gradient parity on the second step."""
 import sys, os
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from util import rel_err
 from oracle import graph
 from transfer_em_amd.cgan import EM2EM

@@ -320,7 +320,7 @@ class EM2EM(object):
         hop=True (stream capture): after every wait a list continues on a FRESH stream that waits for
         the list's previous stream and for the named event.  The dependency graph is the same, but no
         stream ever waits on work that itself waited on that stream -- ROCm 7.2 hipStreamEndCapture
-        crashes on such a zig-zag (reproducer: tests/debug_graph2.py variant 2 vs 3)."""
+        crashes on such a zig-zag (reproducer: tests/tools/debug_graph2.py variant 2 vs 3)."""
         cur = torch.cuda.current_stream()
         st.events["inputs"].record(cur)              # losses cleared + inputs copied
         streams = [cur] + list(st.extra_streams)
