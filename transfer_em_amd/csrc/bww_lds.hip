@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
   const int m = lane & 15, kq = lane >> 4;
 
   // ---- which column of the volume is ours
-  int seg = blockIdx.x;
+  int seg = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);   // neighbouring columns share an XCD's L2
   const int zseg = seg % p.zsegs; seg /= p.zsegs;
   const int ych = seg % p.nych;
   const int n = seg / p.nych;

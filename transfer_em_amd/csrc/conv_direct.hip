@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_direct_k(ConvDev p) {
   constexpr int CI = CI0 + CI1, CO = CO0 + CO1;
   constexpr bool SPLIT = FLIP && CI0 % 2 == 0 && CI1 % 2 == 0;     // see fma_block_split
   constexpr int NACC = SPLIT ? 2 * CO : CO;
-  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t idx = (int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   if (idx >= p.total) return;
   int x = (int)(idx % p.OW); int64_t r = idx / p.OW;
   int y = (int)(r % p.OH); r /= p.OH;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_rows_k(ConvDev p) {
   constexpr bool SPLIT = FLIP && CI0 % 2 == 0 && CI1 % 2 == 0;
   constexpr int NACC = SPLIT ? 2 * CO : CO;
   const int QH = (p.OH + NY - 1) / NY;
-  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t idx = (int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   if (idx >= (int64_t)p.N * p.OD * QH * p.OW) return;
   int x = (int)(idx % p.OW); int64_t r_ = idx / p.OW;
   int yq = (int)(r_ % QH); r_ /= QH;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void convT_direct_k(ConvDev p) {
   int rx = cls % p.sw, ry = (cls / p.sw) % p.sh, rz = cls / (p.sw * p.sh);
   int QW = (p.OW - rx + p.sw - 1) / p.sw, QH = (p.OH - ry + p.sh - 1) / p.sh, QD = (p.OD - rz + p.sd - 1) / p.sd;
   int64_t cnt = (int64_t)p.N * QD * QH * QW;
-  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t idx = (int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   if (idx >= cnt) return;
   int qx = (int)(idx % QW); int64_t r = idx / QW;
   int qy = (int)(r % QH); r /= QH;
@@ -344,7 +344,7 @@ int fill_dev(const tem_conv_args *a, ConvDev &p, bool transposed) {
 __global__ __launch_bounds__(256) void conv_generic_k(ConvDev p, int CI0, int CI1, int CO0, int CO1, int flip,
                                                       int transposed) {
   const int CI = CI0 + CI1, CO = CO0 + CO1;
-  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t idx = (int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   if (idx >= p.total * CO) return;
   const int co = (int)(idx % CO); int64_t r = idx / CO;
   int x = (int)(r % p.OW); r /= p.OW;

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps tile bookkeeping on the scalar unit
   const int m = lane & 15, kq = lane >> 4;
 
-  int seg = blockIdx.x;
+  int seg = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);   // neighbouring columns share an XCD's L2
   const int zseg = seg % p.zsegs; seg /= p.zsegs;
   const int ych = seg % p.nych;
   const int n = seg / p.nych;
