@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--dimsize", type=int, default=132)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--no-kernel-profile", action="store_true",
+                    help="only the timed steps (counter-collection runs of profiles/collect_round.sh); no JSON line")
     ap.add_argument("--graph", action="store_true", help="replay the step as captured HIP graphs instead of eager launches")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the step on one stream (kernel durations free of overlap: use under rocprofv3 to "
@@ -130,6 +132,8 @@ def main():
     assert np.isfinite(losses).all(), losses
 
     out = None
+    if args.no_kernel_profile:
+        return
     if rank == 0:
         st = model._steps[B]
         nprof = max(2, min(5, args.steps))
@@ -145,8 +149,9 @@ def main():
         else:
             roof = dict(bound="hbm", achieved=dom["bytes"] / secs / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM bytes per launch of this kernel from the PMC passes (profiles/collect_traffic.py; the counters
-        # cannot be read inside this process) -- measured on the kernel's full-size launch; null if not profiled
+        # HBM bytes per launch of this kernel from the PMC passes of profiles/collect_round.sh (the counters cannot
+        # be read inside this process): average over the same launches of the train step that `achieved` averages
+        # over; null if the kernel has not been profiled
         roof["traffic"] = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))

@@ -8,10 +8,13 @@ OUT=$ROOT/gpurun_out/round
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py --steps 20 --warmup 3 --kernel-table > $OUT/bench.json 2> $OUT/kernel_table.txt
+rm -rf $OUT/prof_single $OUT/prof_3streams
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_single -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --single-stream > $OUT/bench_single_stream_under_rocprof.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_3streams -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_3streams_under_rocprof.json 2> /dev/null
-LAYERS="f1 bdd_f1 mid bdd_mid bww_f1 bww_d1a d1a bd_d1a"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tests/microbench.py $LAYERS --iters=3 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tests/microbench.py $LAYERS --iters=3 > /dev/null 2>&1
+# HBM traffic counters over the SAME launches the roofline averages over (all launches of each kernel in bench's
+# train steps, one stream), one counter per pass as MI355X_MICROARCH.md prescribes
+rm -rf $OUT/pmc_fetch $OUT/pmc_write
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-stream --no-kernel-profile > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-stream --no-kernel-profile > /dev/null 2>&1
 python3 $ROOT/profiles/collect_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/hbm_traffic.json > $OUT/traffic.txt
 ls $OUT
