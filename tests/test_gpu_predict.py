@@ -50,3 +50,34 @@ def test_predict_cube_matches_tilewise_oracle(oracle_lib, tmp_path):
     diff = np.minimum(np.abs(diff), 256 - np.abs(diff))                     # uint8 wrap distance
     assert (diff > 1).sum() == 0 and (diff != 0).mean() < 0.01              # fp32 vs double accumulation at .5 ties
     assert got.std() > 20                                                    # not a degenerate image
+
+
+def test_simple_training_notebook_flow(tmp_path, capsys):
+    """examples/simple_training.ipynb:52-77 end to end on the HIP path: uint8 images -> reflect-padded,
+    standardised datasets -> EM2EM(132, 2-D).train(...) with a checkpoint per epoch -> predict -> restore."""
+    import glob
+    from transfer_em_amd.cgan import EM2EM
+    from transfer_em_amd.datasets.datasets import create_dataset_from_tensors, unstandardize_population
+    rng = np.random.default_rng(0)
+    imgs_x = [rng.integers(0, 256, (128, 128), dtype=np.uint8) for _ in range(6)]
+    imgs_y = [(rng.integers(0, 256, (128, 128)) // 2 + 64).astype(np.uint8) for _ in range(6)]
+    pad = [[2, 2], [2, 2]]
+    ds_x, ms_x = create_dataset_from_tensors(imgs_x, batch_size=2, padding=pad, enable_augmentation=True, randomize=True)
+    ds_y, ms_y = create_dataset_from_tensors(imgs_y, batch_size=2, padding=pad, enable_augmentation=True, randomize=True)
+    sample = next(iter(ds_x))
+    assert sample.shape == (2, 132, 132, 1)
+    model = EM2EM(132, "notebook", is3d=False, checkpoint_root=str(tmp_path))
+    before = model.generator_g.params.theta.clone()
+    model.train(ds_x, ds_y, epochs=2, check_freq=1)
+    out = capsys.readouterr().out
+    assert out.count("Epoch") == 2 and out.count("Saving checkpoint") == 2
+    assert len(glob.glob(str(tmp_path / "train_notebook" / "ckpt-*.pt"))) == 2
+    assert int(model.step_dev.item()) == 2 * len(ds_x) == 6
+    assert not torch.equal(before, model.generator_g.params.theta)
+    pred = model.predict(sample)                                   # (2, 1, 96, 96, 1): outdimsize window
+    assert tuple(pred.shape) == (2, 1, model.outdimsize, model.outdimsize, 1) and model.outdimsize == 96
+    img = unstandardize_population(pred.cpu().numpy(), ms_y)
+    assert np.isfinite(img).all()
+    again = EM2EM(132, "notebook", is3d=False, checkpoint_root=str(tmp_path))      # resumes from the latest
+    assert torch.equal(again.generator_g.params.theta, model.generator_g.params.theta)
+    assert torch.equal(again.predict(sample), pred)
