@@ -133,6 +133,8 @@ def main():
 
     out = None
     if args.no_kernel_profile:
+        if rank == 0:
+            print(f"ms_per_step {dt / args.steps * 1e3:.3f} (timed steps only, no JSON)", file=sys.stderr)
         return
     if rank == 0:
         st = model._steps[B]

@@ -136,7 +136,7 @@ class _CompiledStep:
         #         the adversarial term (joined into the generator sweep) -> discriminator sweep -> reduction
         L_ = lambda *plans: [l for pl in plans for l in pl.launches]
         main, side, third = [], [], []
-        # side: discriminators
+        # side: discriminators (one stream for both: a stream per discriminator measured no different)
         side += [("wait", "inputs")] + L_(d_xr, d_yr)
         side += [("wait", "fake_y")] + L_(d_yf) + [("wait", "fake_x")] + L_(d_xf)
         side += [loss[0], loss[1]] + loss[6:10] + L_(a_dy, a_dx) + [("record", "adv")]
