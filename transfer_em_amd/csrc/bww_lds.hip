@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NW * 64) void bww_lds_k(Dev p) {
 constexpr int LDS_BUDGET = 150 * 1024;
 static thread_local char *g_name = nullptr;
 static thread_local int g_name_len = 0;
-constexpr int TARGET_BLOCKS = 512;
+constexpr int TARGET_BLOCKS = 256;   // one workgroup per CU: swept 128..1024 on the 132^3 step (TEM_BWW_BLOCKS), 256 is fastest
 
 static uint32_t magic_for(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
 
