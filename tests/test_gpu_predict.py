@@ -81,3 +81,31 @@ def test_simple_training_notebook_flow(tmp_path, capsys):
     again = EM2EM(132, "notebook", is3d=False, checkpoint_root=str(tmp_path))      # resumes from the latest
     assert torch.equal(again.generator_g.params.theta, model.generator_g.params.theta)
     assert torch.equal(again.predict(sample), pred)
+
+
+def test_saved_model_export_and_tiled_predict(tmp_path):
+    """utils.save_model -> predict_cube_from_saved_model (utils.py:12-38,133-167): the exported generator
+    reproduces the live model's tiled prediction; a path instead of an array is refused (no cloud store)."""
+    from transfer_em_amd.cgan import EM2EM
+    from transfer_em_amd import utils
+    rng = np.random.default_rng(3)
+    model = EM2EM(74, "export", checkpoint_root=str(tmp_path))
+    x = torch.from_numpy(rng.standard_normal((1, 74, 74, 74, 1)).astype(np.float32))
+    model.train_step(x, x)
+    ckpt = model.make_checkpoint(1)
+    ms_x, ms_y = (0.1, 1.2), (-0.2, 0.9)
+    out_dir = str(tmp_path / "exported")
+    import os
+    cwd = os.getcwd()
+    os.chdir(tmp_path)                       # save_model restores through EM2EM(..., ckpt_restore=...): its own ./checkpoints
+    try:
+        utils.save_model(out_dir, ckpt, ms_x, ms_y, size=74, is3d=True)
+    finally:
+        os.chdir(cwd)
+    vol = rng.integers(0, 256, (50, 60, 70), dtype=np.uint8)
+    start, size = (3, 5, 2), (45, 41, 40)
+    live = utils.predict_ng_cube(vol, start, size, model, ms_x, ms_y)
+    saved = utils.predict_cube_from_saved_model(vol, start, size, None, out_dir)
+    assert live.shape == (40, 41, 45) and np.array_equal(live, saved)
+    with pytest.raises(NotImplementedError):
+        utils.predict_ng_cube("gs://bucket/volume", start, size, model, ms_x, ms_y)

@@ -56,3 +56,27 @@ def test_tile_plan_matches_reference_logic():
 def test_shard_helpers():
     from transfer_em_amd import distributed as D
     assert D.shard(range(7), 1, 3) == [1, 4] and D.replica_seed(42, 3) == 45
+
+
+def test_reference_package_name_is_an_alias():
+    """`import transfer_em...` (the reference's package name, as the example notebooks spell it) yields the
+    same module objects as `transfer_em_amd...`."""
+    import transfer_em
+    import transfer_em_amd
+    from transfer_em.cgan import EM2EM, CycleGan, create_prior_helper
+    from transfer_em.datasets import datasets
+    from transfer_em import debug
+    from transfer_em.models.generator import unet_generator, create_generator
+    from transfer_em.models.discriminator import discriminator, create_discriminator
+    from transfer_em.utils import predict_cube_from_saved_model, predict_ng_cube, save_model
+    import transfer_em_amd.cgan
+    assert transfer_em is transfer_em_amd and EM2EM is transfer_em_amd.cgan.EM2EM and CycleGan is EM2EM
+    assert datasets is transfer_em_amd.datasets.datasets and debug is transfer_em_amd.debug
+    assert create_generator is unet_generator and create_discriminator is discriminator
+    import inspect
+    assert list(inspect.signature(predict_ng_cube).parameters) == [
+        "location", "start", "size", "model", "meanstd_x", "meanstd_y", "cloudrun", "fetch_input", "outdimsize", "buffer"]
+    assert list(inspect.signature(predict_cube_from_saved_model).parameters) == [
+        "location", "start", "size", "cloudrun", "model_dir", "fetch_input"]
+    assert list(inspect.signature(EM2EM.__init__).parameters)[1:9] == [
+        "dimsize", "exp_name", "is3d", "norm_type", "ckpt_restore", "wf", "focal_gamma", "disc_prior"]

@@ -106,9 +106,26 @@ class _SavedGenerator:
         return self.generator_g(data)
 
 
-def predict_cube_from_saved_model(volume, start, size, model_dir, fetch_input=False):
-    """Local-array form of reference predict_cube_from_saved_model (utils.py:12-38)."""
+def _local_volume(location):
+    if isinstance(location, (str, bytes, os.PathLike)):
+        raise NotImplementedError("cloud volume stores (neuroglancer precomputed, utils.py:62-90) are out of scope: "
+                                  "pass the uint8 volume as an array indexed [z, y, x]")
+    return location
+
+
+def predict_ng_cube(location, start, size, model, meanstd_x, meanstd_y, cloudrun=None, fetch_input=False,
+                    outdimsize=None, buffer=None):
+    """Reference signature (utils.py:41): `location` is the uint8 volume itself (array indexed [z, y, x])
+    instead of a cloud path; `cloudrun` is accepted and ignored."""
+    return predict_cube(_local_volume(location), start, size, model, meanstd_x, meanstd_y, fetch_input=fetch_input,
+                        outdimsize=outdimsize, buffer=buffer)
+
+
+def predict_cube_from_saved_model(location, start, size, cloudrun, model_dir, fetch_input=False):
+    """Reference signature (utils.py:12-38) over a local array: `location` is the uint8 volume,
+    `cloudrun` is accepted and ignored, `model_dir` is a directory written by save_model."""
     from .models.generator import unet_generator
+    volume = _local_volume(location)
     meta = json.load(open(os.path.join(model_dir, 'meta.json')))
     blob = torch.load(os.path.join(model_dir, "generator_g.pt"), map_location="cpu", weights_only=True)
     gen, _ = unet_generator(blob["dimsize"], blob["is3d"])
