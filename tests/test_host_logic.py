@@ -80,3 +80,21 @@ def test_reference_package_name_is_an_alias():
         "location", "start", "size", "cloudrun", "model_dir", "fetch_input"]
     assert list(inspect.signature(EM2EM.__init__).parameters)[1:9] == [
         "dimsize", "exp_name", "is3d", "norm_type", "ckpt_restore", "wf", "focal_gamma", "disc_prior"]
+
+
+def test_warp_tensor_blur_and_holes():
+    """debug.warp_tensor (reference debug.py:7-63): box blur with zero SAME padding; holes take the image mean."""
+    from transfer_em_amd.debug import warp_tensor
+    x = np.zeros((9, 9, 1), np.float32); x[4, 4, 0] = 9.0
+    class NoHoles:                         # uniform() never below the hole rate
+        def uniform(self, lo, hi, shape): return np.ones(shape)
+    y = warp_tensor(x, NoHoles())
+    assert y.shape == (9, 9, 1) and np.allclose(y[3:6, 3:6, 0], 1.0) and y[:, :, 0].sum() == 9.0
+    corner = np.ones((5, 5, 5, 1), np.float32)
+    assert np.isclose(warp_tensor(corner, NoHoles())[0, 0, 0, 0], 8 / 27)     # zero padding at the border
+    class OneHole:
+        def uniform(self, lo, hi, shape):
+            u = np.ones(shape); u[4, 4] = 0.0; return u
+    z = warp_tensor(x, OneHole())[..., 0]
+    mean = np.float32(9.0 / 81)
+    assert np.allclose(z[2:6, 2:6], mean) and z[1, 4] == 0.0 and z[6, 6] == 0.0      # SAME, k=4: the hole at 4 marks outputs 3..6 - 1 = 2..5

@@ -3,6 +3,33 @@ import numpy as np
 import torch
 
 
+_WARP_RNG = np.random.default_rng(0)
+
+
+def warp_tensor(tensor, rng=None):
+    """Artificial source domain for self-comparison tests (reference debug.py:7-63): box blur (3 per axis, zero
+    'SAME' padding) plus random 'holes' (rate 4/128^2 of the voxels, dilated by a 4-wide box with TensorFlow's
+    SAME alignment: 1 before, 2 after) set to the image mean.  `tensor`: (H, W, 1) or (D, H, W, 1), already
+    scaled to [-1, 1]; pass it as `custom_map` to dataset creation.  Host-side numpy (data preparation, not the
+    hot path); the hole positions come from numpy's generator, not TensorFlow's."""
+    rng = _WARP_RNG if rng is None else rng
+    t = np.asarray(tensor, np.float32)
+    nd = t.ndim - 1
+    x = t[..., 0]
+    blur = np.zeros_like(x)
+    pad = np.pad(x, 1)                                    # zeros: conv 'SAME'
+    for off in np.ndindex(*([3] * nd)):
+        blur += pad[tuple(slice(o, o + n) for o, n in zip(off, x.shape))]
+    blur /= np.float32(3 ** nd)
+    holes = rng.uniform(0.0, 1.0, x.shape) < 4.0 / (128 * 128)
+    grown = np.zeros(x.shape, bool)
+    hp = np.pad(holes, [(1, 2)] * nd)                     # even kernel, SAME: pad_before 1, pad_after 2
+    for off in np.ndindex(*([4] * nd)):
+        grown |= hp[tuple(slice(o, o + n) for o, n in zip(off, x.shape))]
+    out = np.where(grown, blur.mean(dtype=np.float32), blur).astype(np.float32)
+    return out[..., None]
+
+
 def accuracy(unwarped_orig_tensor, predicted_tensor):
     """Root-mean-squared error between two tensors (tf.keras.metrics.RootMeanSquaredError, debug.py:65-71)."""
     a = torch.as_tensor(unwarped_orig_tensor).detach().to("cpu", torch.float64)
