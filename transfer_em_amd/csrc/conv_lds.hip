@@ -66,7 +66,8 @@ struct Dev {
   uint32_t magicX, magicWP, magicSeg;
   int32_t chunksX;
   unsigned long long *stamps;    // diagnostic: per-phase cycle sums [block][wave][8] (null in normal runs)
-  int32_t patch;                 // epilogue transpose: 1 = through a 16 x 20 LDS patch per wave, 0 = ds_bpermute (no LDS)
+  int32_t patch;                 // epilogue transpose: row pitch (floats) of the 16-row LDS patch per wave (20: conflict-free,
+                                 // 16: 4-way conflicts on its four writes, 2 KB less); 0 = ds_bpermute (no LDS)
   int32_t dbg;                   // ablation switches (TEM_DEBUG_FLAGS env, perf triage only): 1 no stores, 2 no MFMA, 4 no prefetch
   Ep32 ep;
 };
@@ -74,7 +75,7 @@ struct Dev {
 template <int CI, int CO, int K, int S, int NW, int MAXPFX, int MTW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   constexpr int CIP = CI + 2, NT = (CO + 15) / 16, KS = CI / 4, NTHR = NW * 64, NTAP = K * K * K;
-  constexpr int TAIL = S == 1 ? 20 : 40;                  // voxels the last tiles over-read past the ring
+  constexpr int TAIL = S == 1 ? 18 : 40;                  // voxels the last tiles over-read past the ring (S == 1: <= 17)
   static_assert(CI % 16 == 0 && NW % NT == 0, "C_in 16 or 32: an even number of k-step pairs per tap");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rowpitch = p.WP * CIP;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
   // come from one Philox call.  The transpose goes through a private 1.25 KB LDS patch per wave, or -- when
   // those 10 KB are what keeps one more output row per workgroup out of the 160 KB (p.patch == 0, host's
   // choice) -- through ds_bpermute (the LDS crossbar, no storage, ~900 cycles more per tile).
-  constexpr int TPITCH = 20;                              // floats per row of the transpose patch
+  const int TPITCH = p.patch;                             // floats per row of the transpose patch
   float *tp = lds + ((K * slotpitch + TAIL * CIP + 3) & ~3) + wave * (16 * TPITCH);   // 16-byte aligned
   const int ti = lane >> 2, tcq = lane & 3;               // transposed role: voxel row, channel quad
   const int tco = nt * 16 + tcq * 4;
@@ -473,9 +474,9 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
   for (int r = 1; r <= (p.OH < 16 ? p.OH : 16); ++r) {
     int YR = (r - 1) * S + K;
     int ntiles = S == 1 ? (r * p.WP + 15) / 16 : r * p.nseg;
-   for (int patch = 1; patch >= 0; --patch) {
-    // ring + tail the last tiles over-read (+ one 16 x 20 transpose patch per wave)
-    size_t bytes = ((size_t)K * YR * p.WP * CIP + (S == 1 ? 20 : 40) * CIP + 4 + (patch ? NW * 16 * 20 : 0)) * 4;
+   for (int patch = 20; patch >= 0; patch = patch == 20 ? 16 : (patch == 16 ? 0 : -1)) {
+    // ring + tail the last tiles over-read (+ one 16-row transpose patch per wave)
+    size_t bytes = ((((size_t)K * YR * p.WP * CIP + (S == 1 ? 18 : 40) * CIP + 3) & ~(size_t)3) + NW * 16 * patch) * 4;
     bool fits = bytes <= (size_t)LDS_MAX && (size_t)S * YR * p.chunksX <= (size_t)MAXPFX * (LOADER_ALL ? NTHR : NTHR / 2) &&
                 ntiles * NT <= MTW * NW;
     if (!fits) continue;
@@ -484,7 +485,8 @@ int run(Dev p, hipStream_t st, int mode, double *cost) {
     int cols = p.N * nych;
     if (rounds > MTW) continue;
     double step = 2.0 * MTW * NTAPS * KSTEPS * 32.0 * 1.35 + 2500.0 + 600.0 * MTW;   // every wave runs MTW slots
-    if (!patch) step += 900.0 * MTW;                  // measured: the ds_bpermute transpose costs ~900 cycles per tile
+    if (patch == 16) step += 100.0 * MTW;             // bank conflicts on the patch writes
+    if (patch == 0) step += 2500.0 * MTW;             // measured: the ds_bpermute transpose costs 2-3k cycles per tile
     double pro = 12000.0 + bytes / 12.0;              // first K planes arrive at the CU's HBM share (~12 B/clk)
     for (int zs = 1; zs <= p.OD; ++zs) {
       int zper = (p.OD + zs - 1) / zs, zsegs = (p.OD + zper - 1) / zper;
