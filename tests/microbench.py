@@ -37,6 +37,8 @@ def build(name, direct=False):
         kind, layer = "bdt", name[4:]
     elif name.startswith("ct_"):         # Conv3DTranspose forward (k4 s2 'same')
         kind, layer = "ct", name[3:]
+    elif name.startswith("bdn_"):
+        kind, layer = "bdn", name[4:]
     elif name.startswith("bd_"):
         kind, layer = "bd", name[3:]
     elif name.startswith("bww_"):
@@ -59,6 +61,8 @@ def build(name, direct=False):
         up = rnd(1, 2 * n, 2 * n, 2 * n, CO)
         step = torch.zeros(1, dtype=torch.int32, device=dev)
         return H.conv_launch(name, x, w, up, k, s, 1, transposed=True, slope=0.3, dropout=(42, 1, step), direct=direct)
+    if kind == "bdn":      # input-gradient with PRE-TRANSPOSED weights ([tap][ci][co] layout): timing experiment
+        return H.conv_launch(name, y, w, x, k, 1, k - 1, gate=torch.randn_like(x), direct=direct)
     if kind == "bd":
         return H.conv_launch(name, y, w, x, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI, gate=torch.randn_like(x), direct=direct)
     ws = H.GradWorkspace(_P((k, k, k, CI, CO)), 1)

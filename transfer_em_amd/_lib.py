@@ -85,6 +85,7 @@ _SIGS = {
     "tem_copy_view": [_VP, _VP, C.c_void_p],
     "tem_add_view": [_VP, _VP, C.c_void_p],
     "tem_leaky_gate_view": [_VP, _VP, C.c_float, C.c_void_p],
+    "tem_flip_transpose": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p],
     "tem_abi_version": [C.POINTER(C.c_char_p)],
 }
 EXPORTS = tuple(_SIGS)

@@ -57,6 +57,7 @@ class _CompiledStep:
         drop = lambda call: (m.seed, call, m.step_dev)
         cr = lambda t, c: H.crop(t, c, c, is3d)
         kw = dict(direct=direct)
+        kwb = dict(direct=direct, refresh_wt=False)       # theta_t is refreshed once per network below
 
         # ---- forward (cgan.py:152-189)
         f_g1 = GenForward(G, self.real_x, training=True, drop=drop(CALL_G_FAKE_Y), **kw)
@@ -101,21 +102,21 @@ class _CompiledStep:
         # ---- backward.  Each weight-gradient pass writes its own partial-sum slabs (GradWorkspace).
         wg, wf = H.GradWorkspace(G.params, 3), H.GradWorkspace(F.params, 3)
         wdx, wdy = H.GradWorkspace(DX.params, 2), H.GradWorkspace(DY.params, 2)
-        b_g3 = GenBackward(f_g3, dsame_y, wg, 0, **kw)
-        b_f3 = GenBackward(f_f3, dsame_x, wf, 0, **kw)
-        b_f2 = GenBackward(f_f2, dcyc_x, wf, 1, need_dx=True, **kw)      # dx = d S / d fake_y (cycle part)
-        b_g2 = GenBackward(f_g2, dcyc_y, wg, 1, need_dx=True, **kw)
+        b_g3 = GenBackward(f_g3, dsame_y, wg, 0, **kwb)
+        b_f3 = GenBackward(f_f3, dsame_x, wf, 0, **kwb)
+        b_f2 = GenBackward(f_f2, dcyc_x, wf, 1, need_dx=True, **kwb)      # dx = d S / d fake_y (cycle part)
+        b_g2 = GenBackward(f_g2, dcyc_y, wg, 1, need_dx=True, **kwb)
         # adversarial part through the discriminators (input gradient only), summed onto the cycle part
-        a_dy = DiscBackward(d_yf, dz_gen_g, need_dx=True, need_dw=False, **kw)
-        a_dx = DiscBackward(d_xf, dz_gen_f, need_dx=True, need_dw=False, **kw)
+        a_dy = DiscBackward(d_yf, dz_gen_g, need_dx=True, need_dw=False, **kwb)
+        a_dx = DiscBackward(d_xf, dz_gen_f, need_dx=True, need_dw=False, **kwb)
         add_y = H.copy_view_launch("dfake_y+=adv", a_dy.dx, b_f2.dx, add=True)
         add_x = H.copy_view_launch("dfake_x+=adv", a_dx.dx, b_g2.dx, add=True)
-        b_g1 = GenBackward(f_g1, b_f2.dx, wg, 2, **kw)
-        b_f1 = GenBackward(f_f1, b_g2.dx, wf, 2, **kw)
-        w_dxr = DiscBackward(d_xr, dz_rx, wdx, 0, **kw)
-        w_dxf = DiscBackward(d_xf, dz_fx, wdx, 1, **kw)
-        w_dyr = DiscBackward(d_yr, dz_ry, wdy, 0, **kw)
-        w_dyf = DiscBackward(d_yf, dz_fy, wdy, 1, **kw)
+        b_g1 = GenBackward(f_g1, b_f2.dx, wg, 2, **kwb)
+        b_f1 = GenBackward(f_f1, b_g2.dx, wf, 2, **kwb)
+        w_dxr = DiscBackward(d_xr, dz_rx, wdx, 0, **kwb)
+        w_dxf = DiscBackward(d_xf, dz_fx, wdx, 1, **kwb)
+        w_dyr = DiscBackward(d_yr, dz_ry, wdy, 0, **kwb)
+        w_dyf = DiscBackward(d_yf, dz_fy, wdy, 1, **kwb)
         self.bwd = dict(g3=b_g3, f3=b_f3, f2=b_f2, g2=b_g2, ady=a_dy, adx=a_dx, g1=b_g1, f1=b_f1,
                         dxr=w_dxr, dxf=w_dxf, dyr=w_dyr, dyf=w_dyf)
         backward = []
@@ -126,7 +127,8 @@ class _CompiledStep:
             backward += p.launches
         red = {k: w.reduce_launches(k) for k, w in (("g", wg), ("f", wf), ("dx", wdx), ("dy", wdy))}
         reduce_ = red["g"] + red["f"] + red["dx"] + red["dy"]
-        self.compute = forward + loss + backward + reduce_          # flat order (single stream, profiling)
+        flips = {k: net.params.flip_transpose_launch(k + ".flip_transpose") for k, net in (("g", G), ("f", F), ("dx", DX), ("dy", DY))}
+        self.compute = list(flips.values()) + forward + loss + backward + reduce_   # flat order (single stream, profiling)
         self._keep = (wg, wf, wdx, wdy, dz_gen_g, dz_gen_f, dz_rx, dz_fx, dz_ry, dz_fy, dcyc_x, dcyc_y, dsame_x, dsame_y)
 
         # ---- two-stream schedule.  The discriminators' layers are small (20^3 .. 8^3 voxels deep in the
@@ -137,7 +139,7 @@ class _CompiledStep:
         L_ = lambda *plans: [l for pl in plans for l in pl.launches]
         main, side, third = [], [], []
         # side: discriminators (one stream for both: a stream per discriminator measured no different)
-        side += [("wait", "inputs")] + L_(d_xr, d_yr)
+        side += [("wait", "inputs"), flips["dx"], flips["dy"]] + L_(d_xr, d_yr)
         side += [("wait", "fake_y")] + L_(d_yf) + [("wait", "fake_x")] + L_(d_xf)
         side += [loss[0], loss[1]] + loss[6:10] + L_(a_dy, a_dx) + [("record", "adv")]
         side += L_(w_dxr, w_dxf, w_dyr, w_dyf) + red["dx"] + red["dy"] + [("record", "side_done")]
@@ -146,8 +148,8 @@ class _CompiledStep:
         # generators' kernel-gradient launches to two more streams (16.4 vs 15.75 ms/step -- the extra
         # LDS-bound kernels only steal CUs from the dependent chains) and HIP stream priorities for the
         # chains (17.9 ms/step).
-        main += L_(f_g1) + [("record", "fake_y")] + L_(f_g3) + [("wait", "fake_x")] + L_(f_g2)
-        third += [("wait", "inputs")] + L_(f_f1) + [("record", "fake_x")] + L_(f_f3) + [("wait", "fake_y")] + L_(f_f2)
+        main += [flips["g"]] + L_(f_g1) + [("record", "fake_y")] + L_(f_g3) + [("wait", "fake_x")] + L_(f_g2)
+        third += [("wait", "inputs"), flips["f"]] + L_(f_f1) + [("record", "fake_x")] + L_(f_f3) + [("wait", "fake_y")] + L_(f_f2)
         main += [loss[3], loss[4]] + L_(b_g3, b_g2) + [("record", "d_fake_x")]
         third += [loss[2], loss[5]] + L_(b_f3, b_f2) + [("record", "d_fake_y")]
         main += [("wait", "adv"), ("wait", "d_fake_y"), add_y] + L_(b_g1) + red["g"]

@@ -264,6 +264,38 @@ extern "C" int tem_add_view(const tem_view *src, const tem_view *dst, tem_stream
   return TEM_OK;
 }
 
+// theta_t = every conv kernel of a flat parameter vector with its taps reversed and (ci, co) transposed:
+//   theta_t[off + ((ntap-1-t)*co + b)*ci + a] = theta[off + (t*ci + a)*co + b];  elements outside the table are copied.
+__global__ __launch_bounds__(256) void flip_transpose_k(const float *__restrict__ theta, float *__restrict__ theta_t,
+                                                        const tem_wlayer *__restrict__ layers, int nlayers, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t dst = i;
+    for (int l = 0; l < nlayers; ++l) {
+      const tem_wlayer L = layers[l];
+      const int64_t rel = i - L.offset, n = (int64_t)L.ntap * L.ci * L.co;
+      if (rel >= 0 && rel < n) {
+        const int b = (int)(rel % L.co);
+        const int64_t ta = rel / L.co;
+        const int a = (int)(ta % L.ci), t = (int)(ta / L.ci);
+        dst = L.offset + ((int64_t)(L.ntap - 1 - t) * L.co + b) * L.ci + a;
+        break;
+      }
+    }
+    theta_t[dst] = theta[i];
+  }
+}
+
+extern "C" int tem_flip_transpose(const float *theta, float *theta_t, const tem_wlayer *layers_dev, int32_t nlayers,
+                                  int64_t total, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!theta || !theta_t || theta == theta_t || nlayers < 0 || (nlayers > 0 && !layers_dev) || total < 0) return TEM_EINVAL;
+  if (total == 0) return TEM_OK;
+  hipLaunchKernelGGL(flip_transpose_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, theta, theta_t, layers_dev,
+                     nlayers, total);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
 extern "C" int tem_leaky_gate_view(const tem_view *g, const tem_view *saved, float slope, tem_stream_t stream) {
   TEM_CLEAR_ERR();
   if (!g || !saved || !tem_view_ok(*g) || !tem_view_ok(*saved)) return TEM_EINVAL;

@@ -322,6 +322,13 @@ def copy_view_launch(name, src, dst, add=False):
     return Launch(fn, (C.byref(vs), C.byref(vd)), name, [src, dst, vs, vd])
 
 
+def flip_transpose_launch(name, theta, theta_t, table_dev, nlayers):
+    """theta_t := tap-reversed, (ci, co)-transposed copy of theta's conv kernels (tem_flip_transpose)."""
+    lib = _lib.load()
+    return Launch(lib.tem_flip_transpose, (theta.data_ptr(), theta_t.data_ptr(), table_dev.data_ptr(), nlayers,
+                                           theta.numel()), name, [theta, theta_t, table_dev])
+
+
 def leaky_gate_launch(name, g, saved, slope):
     """g = saved > 0 ? g : slope * g, in place."""
     lib = _lib.load()

@@ -111,7 +111,7 @@ class DiscBackward:
     """Adjoint of a DiscForward for one upstream gradient dz.  need_dw=False is the
     generator's adversarial path (input gradient only, cgan.py:192-193,207-210)."""
 
-    def __init__(self, fwd, dz, ws=None, call=0, need_dx=False, need_dw=True, direct=False):
+    def __init__(self, fwd, dz, ws=None, call=0, need_dx=False, need_dw=True, direct=False, refresh_wt=True):
         net, A = fwd.net, fwd.act
         P, is3d = net.params, net.is3d
         self.fwd, self.dz = fwd, dz
@@ -119,6 +119,8 @@ class DiscBackward:
         G = self.grads = {k: torch.empty_like(A[k]) for k in order[:-1]}
         self.dx = torch.empty_like(fwd.x) if need_dx else None
         L = self.launches = []
+        if refresh_wt:                       # see GenBackward: theta_t for the wide layers' input-gradients
+            L.append(P.flip_transpose_launch("d.flip_transpose"))
         g_out = dz
         pf = fwd.prior_fwd
         g_feat = torch.empty_like(pf.y) if pf is not None else None
@@ -141,9 +143,12 @@ class DiscBackward:
             if s == 1:
                 # with a prior the gradient of the concat splits: channels 0..31 to the trunk (gated by
                 # Downsample_2's LeakyReLU), the rest, ungated, to the prior's output
-                L.append(H.conv_launch("d.bd." + name, g_out, P.w(name), dst, k, 1, k - 1, is3d=i3,
-                                       out1=g_feat if with_prior else None,
-                                       layout=H.TEM_W_FLIP_CO_CI, gate=gate, gate_slope=gslope, direct=direct))
+                shp = P.shapes[name]
+                use_t = shp[4] >= 16 and shp[3] >= 8
+                L.append(H.conv_launch("d.bd." + name, g_out, P.w_t(name) if use_t else P.w(name), dst, k, 1, k - 1,
+                                       is3d=i3, out1=g_feat if with_prior else None,
+                                       layout=H.TEM_W_TAP_CI_CO if use_t else H.TEM_W_FLIP_CO_CI,
+                                       gate=gate, gate_slope=gslope, direct=direct))
             else:
                 L.append(H.conv_launch("d.bd." + name, g_out, P.w(name), dst, k, s, 0, is3d=i3, transposed=True,
                                        gate=gate, gate_slope=gslope, direct=direct))

@@ -178,7 +178,7 @@ class GenBackward:
     """Adjoint of one GenForward: fills this call's kernel-gradient slabs and, if asked, dx.
     `dy` is the gradient w.r.t. fwd.y (the computed output window)."""
 
-    def __init__(self, fwd, dy, ws, call, need_dx=False, direct=False):
+    def __init__(self, fwd, dy, ws, call, need_dx=False, direct=False, refresh_wt=True):
         net, A, e, R = fwd.net, fwd.act, fwd.edges, fwd.regions
         P, is3d, ch = net.params, net.is3d, fwd.ch
         N, dev = fwd.x.shape[0], fwd.x.device
@@ -208,42 +208,56 @@ class GenBackward:
             return H.bww_launch("g.bww." + name, in0, dout, ws, name, call, k, s, p, is3d=is3d, in1=in1)
 
         L = self.launches = []
+        # Input-gradients of the wide layers read the tap-reversed / transposed kernel copy theta_t as a plain
+        # [tap][ci][co] convolution (contiguous kernel-tap fragments: 27-33 % faster on the LDS-tiled kernels);
+        # the narrow ones keep reading theta in place through the TEM_W_FLIP_CO_CI layout.  refresh_wt: this plan
+        # refreshes theta_t itself (stand-alone use); the train step does it once per network instead.
+        if refresh_wt:
+            L.append(P.flip_transpose_launch("g.flip_transpose"))
+
+        def wb(name):
+            s_ = P.shapes[name]
+            return dict(w=P.w_t(name), layout=AS) if (s_[4] >= 16 and s_[3] >= 8) else dict(w=P.w(name), layout=FL)
+
+        def cvb(lname, gin, name, gout, pad, **k2):
+            wsel = wb(name)
+            return cv(lname, gin, wsel["w"], gout, 3, 1, pad, layout=wsel["layout"], **k2)
         # every input-gradient of a stride-1 VALID conv is a conv with pad k-1 = 2 over the output gradient
         L.append(bww("f2", A["f1"], dy, 3, 1, pc(0, 1, "f1", "f2")))
-        L.append(cv("g.bd.f2", dy, P.w("f2"), G["f1"], 3, 1, pc(2, 1, "f2", "f1"), layout=FL, gate=A["f1"], **kw))
+        L.append(cvb("g.bd.f2", dy, "f2", G["f1"], pc(2, 1, "f2", "f1"), gate=A["f1"], **kw))
         L.append(bww("f1", A["u1b"], G["f1"], 3, 1, pc(0, 1, "u1b", "f1"), in1=fwd.skip0))
-        L.append(cv("g.bd.f1", G["f1"], P.w("f1"), G["u1b"], 3, 1, pc(2, 1, "f1", "u1b"), layout=FL, out1=t_skip0,
+        L.append(cvb("g.bd.f1", G["f1"], "f1", G["u1b"], pc(2, 1, "f1", "u1b"), out1=t_skip0,
                     gate=A["u1b"], dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), **kw))
         L.append(bww("u1b", G["u1b"], A["u1a"], 4, 2, pc(1, 2, "u1b", "u1a")))
         L.append(cv("g.bd.u1b", G["u1b"], P.w("u1b"), G["u1a"], 4, 2, pc(1, 2, "u1b", "u1a"), layout=AS,
                     gate=A["u1a"], **kw))
         L.append(bww("u1a", A["mid"], G["u1a"], 3, 1, pc(0, 1, "mid", "u1a")))
-        L.append(cv("g.bd.u1a", G["u1a"], P.w("u1a"), G["mid"], 3, 1, pc(2, 1, "u1a", "mid"), layout=FL,
+        L.append(cvb("g.bd.u1a", G["u1a"], "u1a", G["mid"], pc(2, 1, "u1a", "mid"),
                     gate=A["mid"], **kw))
         L.append(bww("mid", A["u2b"], G["mid"], 3, 1, pc(0, 1, "u2b", "mid"), in1=fwd.skip1))
-        L.append(cv("g.bd.mid", G["mid"], P.w("mid"), G["u2b"], 3, 1, pc(2, 1, "mid", "u2b"), layout=FL, out1=t_skip1,
+        L.append(cvb("g.bd.mid", G["mid"], "mid", G["u2b"], pc(2, 1, "mid", "u2b"), out1=t_skip1,
                     gate=A["u2b"], dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]), **kw))
         L.append(bww("u2b", G["u2b"], A["u2a"], 4, 2, pc(1, 2, "u2b", "u2a")))
         L.append(cv("g.bd.u2b", G["u2b"], P.w("u2b"), G["u2a"], 4, 2, pc(1, 2, "u2b", "u2a"), layout=AS,
                     gate=A["u2a"], **kw))
         L.append(bww("u2a", A["d2b"], G["u2a"], 3, 1, pc(0, 1, "d2b", "u2a")))
-        L.append(cv("g.bd.u2a", G["u2a"], P.w("u2a"), G["d2b"], 3, 1, pc(2, 1, "u2a", "d2b"), layout=FL,
+        L.append(cvb("g.bd.u2a", G["u2a"], "u2a", G["d2b"], pc(2, 1, "u2a", "d2b"),
                     gate=A["d2b"], **kw))
         L.append(bww("d2b", A["d2a"], G["d2b"], 4, 2, pc(0, 2, "d2a", "d2b")))
         L.append(cv("g.bd.d2b", G["d2b"], P.w("d2b"), G["d2a"], 4, 2, pt(0, 2, "d2b", "d2a"), transposed=True,
                     add=t_skip1, add_off=lo("u2b") + fwd.lo1 - lo("d2a"), gate=A["d2a"], **kw))
         L.append(bww("d2a", A["d1b"], G["d2a"], 3, 1, pc(0, 1, "d1b", "d2a")))
-        L.append(cv("g.bd.d2a", G["d2a"], P.w("d2a"), G["d1b"], 3, 1, pc(2, 1, "d2a", "d1b"), layout=FL,
+        L.append(cvb("g.bd.d2a", G["d2a"], "d2a", G["d1b"], pc(2, 1, "d2a", "d1b"),
                     gate=A["d1b"], **kw))
         L.append(bww("d1b", A["d1a"], G["d1b"], 4, 2, pc(0, 2, "d1a", "d1b")))
         L.append(cv("g.bd.d1b", G["d1b"], P.w("d1b"), G["d1a"], 4, 2, pt(0, 2, "d1b", "d1a"), transposed=True,
                     add=t_skip0, add_off=lo("u1b") + fwd.lo0 - lo("d1a"), gate=A["d1a"], **kw))
         L.append(bww("d1a", A["c0"], G["d1a"], 3, 1, pc(0, 1, "c0", "d1a")))
-        L.append(cv("g.bd.d1a", G["d1a"], P.w("d1a"), G["c0"], 3, 1, pc(2, 1, "d1a", "c0"), layout=FL,
+        L.append(cvb("g.bd.d1a", G["d1a"], "d1a", G["c0"], pc(2, 1, "d1a", "c0"),
                     gate=A["c0"], **kw))
         L.append(bww("c0", fwd.x, G["c0"], 3, 1, fwd.in_pad - lo("c0")))        # x is the full input tensor
         if need_dx:
-            L.append(cv("g.bd.c0", G["c0"], P.w("c0"), self.dx, 3, 1, 2 - fwd.in_pad + lo("c0"), layout=FL, **kw))
+            L.append(cvb("g.bd.c0", G["c0"], "c0", self.dx, 2 - fwd.in_pad + lo("c0"), **kw))
         self._keep = (t_skip0, t_skip1)
 
     def run(self, stream=None):

@@ -24,6 +24,19 @@ class ParamSet:
         self.grad = torch.zeros_like(self.theta)
         self.m = torch.zeros_like(self.theta)
         self.v = torch.zeros_like(self.theta)
+        # tap-reversed, (ci, co)-transposed copy of every kernel for the input-gradient convolutions
+        # (tem_flip_transpose; refreshed once per step by the launch `flip_transpose_launch()` returns)
+        self.theta_t = torch.zeros_like(self.theta)
+        tab = []
+        for k, s in self.shapes.items():
+            if len(s) == 5:
+                tab.append((self.offsets[k], int(np.prod(s[:3])), int(s[3]), int(s[4])))
+        host = np.zeros(len(tab), dtype=np.dtype([("offset", "<i8"), ("ntap", "<i4"), ("ci", "<i4"), ("co", "<i4"),
+                                                   ("pad", "<i4")]))        # sizeof(tem_wlayer) == 24
+        for i, (o_, nt, ci, co) in enumerate(tab):
+            host[i] = (o_, nt, ci, co, 0)
+        self._wtable = torch.from_numpy(host.view(np.uint8).copy()).to(self.device)
+        self._nlayers = len(tab)
         self.initialize(seed)
 
     def initialize(self, seed=None):
@@ -46,6 +59,15 @@ class ParamSet:
         """1-D slice of theta holding kernel `name`."""
         o = self.offsets[name]
         return self.theta[o:o + int(np.prod(self.shapes[name]))]
+
+    def w_t(self, name):
+        """1-D slice of theta_t: kernel `name` with reversed taps and [co][ci] blocks (see __init__)."""
+        o = self.offsets[name]
+        return self.theta_t[o:o + int(np.prod(self.shapes[name]))]
+
+    def flip_transpose_launch(self, name="flip_transpose"):
+        from .. import hip_ops as H
+        return H.flip_transpose_launch(name, self.theta, self.theta_t, self._wtable, self._nlayers)
 
     def g(self, name):
         o = self.offsets[name]
