@@ -1,6 +1,7 @@
 """Micro-benchmark of single layers (not a test): python tests/microbench.py [layer ...] [--iters N]
 
-Layers: f1 mid d1a u1a d1b (forward), bd_f1 bd_mid bd_d1a (input-gradient), bww_f1 bww_mid bww_d1a bww_f2 bww_c0."""
+Layers: f1 mid d1a u1a d1b ... (forward), bd_<layer> (input-gradient as the train step runs it), bdn_<layer> (input-gradient
+in the flip layout), bdd_<layer> (through Dropout, split outputs), bdt_/ct_ (transposed forms), bww_<layer> (kernel gradient)."""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -49,11 +50,14 @@ def build(name, direct=False):
     w = rnd(k ** 3 * CI * CO) * 0.05
     if kind == "fwd":
         return H.conv_launch(name, x, w, y, k, s, 0, slope=0.3, direct=direct)
+    # input-gradients: the train step reads the pre-transposed kernel copy (plain layout) for layers with
+    # C_out >= 16 and C_in >= 8 and theta in place (flip layout) for the rest -- same choice here
+    blayout = H.TEM_W_TAP_CI_CO if (CO >= 16 and CI >= 8) else H.TEM_W_FLIP_CO_CI
     if kind == "bdd":
         half = CI // 2
         o0, o1 = rnd(1, n, n, n, half), rnd(1, n, n, n, half)
         step = torch.zeros(1, dtype=torch.int32, device=dev)
-        return H.conv_launch(name, y, w, o0, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI, out1=o1, gate=torch.randn_like(o0),
+        return H.conv_launch(name, y, w, o0, k, 1, k - 1, layout=blayout, out1=o1, gate=torch.randn_like(o0),
                              dropout=(42, 1, step), direct=direct)
     if kind == "bdt":
         return H.conv_launch(name, y, w, x, k, s, 0, transposed=True, gate=torch.randn_like(x), direct=direct)
@@ -61,10 +65,10 @@ def build(name, direct=False):
         up = rnd(1, 2 * n, 2 * n, 2 * n, CO)
         step = torch.zeros(1, dtype=torch.int32, device=dev)
         return H.conv_launch(name, x, w, up, k, s, 1, transposed=True, slope=0.3, dropout=(42, 1, step), direct=direct)
-    if kind == "bdn":      # input-gradient with PRE-TRANSPOSED weights ([tap][ci][co] layout): timing experiment
-        return H.conv_launch(name, y, w, x, k, 1, k - 1, gate=torch.randn_like(x), direct=direct)
-    if kind == "bd":
+    if kind == "bdn":      # input-gradient in the flip layout regardless of width (what every layer used before theta_t)
         return H.conv_launch(name, y, w, x, k, 1, k - 1, layout=H.TEM_W_FLIP_CO_CI, gate=torch.randn_like(x), direct=direct)
+    if kind == "bd":
+        return H.conv_launch(name, y, w, x, k, 1, k - 1, layout=blayout, gate=torch.randn_like(x), direct=direct)
     ws = H.GradWorkspace(_P((k, k, k, CI, CO)), 1)
     l = H.bww_launch(name, x, y, ws, "w", 0, k, s, 0)
     ws.finalize()
