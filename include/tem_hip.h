@@ -82,6 +82,15 @@ typedef struct tem_epilogue {
    * drop_dims[0] == 0: out0 itself is the full tensor. */
   int32_t      drop_org[3];
   int32_t      drop_dims[3];
+  /* Optional keep mask of the dropout stream: one bit per element of the dropout frame, bit (e & 7) of byte
+   * (e >> 3) for dense element index e (C_out a multiple of 8: a voxel's channels start on a byte).
+   *   keep_mode 1: the kernel also WRITES the bits it draws (the forward pass of Dropout);
+   *   keep_mode 2: the kernel MAY read the bits instead of re-running Philox (the matching input-gradient; a
+   *                pure speed hint -- the bits are the same either way);
+   *   keep_mode 0 / keep_mask NULL: no mask.
+   * Mode 1 is honoured or the call returns TEM_EUNSUPPORTED. */
+  uint8_t     *keep_mask;
+  int32_t      keep_mode;
 } tem_epilogue;
 
 /* Weight addressing for tem_conv: element (tap, c_in, c_out) of the operator's

@@ -128,6 +128,37 @@ def test_conv_transpose_forward_dropout(H, oracle_lib, CI, CO, n):
     assert 0.45 < (got == 0).mean() < 0.55
 
 
+def test_dropout_keep_mask_written_forward_read_backward(H, oracle_lib):
+    """tem_epilogue.keep_mask: the forward transposed convolution writes the bits of its Philox stream
+    (keep_mode 1), the input-gradient through the same Dropout reads them (keep_mode 2) -- identical to
+    re-running Philox, for the LDS-tiled kernel (split 8|8 outputs) as for the direct one."""
+    rng = np.random.default_rng(11)
+    n = 20
+    x = rnd(rng, 1, n, n, n, 16)
+    w = rnd(rng, 4, 4, 4, 8, 16) * 0.1
+    shape = (1, 2 * n, 2 * n, 2 * n, 8)
+    out = torch.empty(shape, dtype=torch.float32, device="cuda")
+    mask = torch.zeros(int(np.prod(shape)) // 8, dtype=torch.uint8, device="cuda")
+    step = torch.tensor([2], dtype=torch.int32, device="cuda")
+    H.run([H.conv_launch("t", dev(x), dev(w.reshape(-1)), out, 4, 2, 1, transposed=True, slope=0.3,
+                         dropout=(42, 5, step), keep_mask=(mask, 1))])
+    keep = oracle_lib.dropout_mask(shape, 42, 5, 2)
+    assert np.array_equal(np.unpackbits(mask.cpu().numpy(), bitorder="little").astype(bool), keep.reshape(-1))
+    g = rnd(rng, 1, 2 * n - 2, 2 * n - 2, 2 * n - 2, 16)
+    wf = rnd(rng, 3, 3, 3, 16, 16) * 0.1
+    for direct in (False, True):
+        res = []
+        for km in (None, (mask, 2)):
+            d0 = torch.empty(shape, dtype=torch.float32, device="cuda")
+            d1 = torch.empty(shape, dtype=torch.float32, device="cuda")
+            launch = H.conv_launch("t", dev(g), dev(wf.reshape(-1)), d0, 3, 1, 2, layout=H.TEM_W_FLIP_CO_CI, out1=d1,
+                                   gate=out, dropout=(42, 5, step), keep_mask=km, direct=direct)
+            H.run([launch])
+            res.append((d0.cpu().numpy(), d1.cpu().numpy(), launch.meta["kernel"]))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), res[0][2]
+        assert (res[0][0] == 0).mean() > 0.45
+
+
 @pytest.mark.parametrize("CI,CO,n", [(32, 16, 6), (16, 8, 7)])
 def test_conv_transpose_input_gradient(H, oracle_lib, CI, CO, n):
     rng = np.random.default_rng(CO)

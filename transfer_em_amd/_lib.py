@@ -36,7 +36,8 @@ class tem_epilogue(C.Structure):
                 ("gate", tem_view), ("gate_slope", C.c_float),
                 ("add", tem_view), ("add_off", C.c_int32 * 3),
                 ("dropout", C.c_int32), ("seed", C.c_uint64), ("site", C.c_uint32), ("step", C.c_uint32),
-                ("step_dev", C.c_void_p), ("drop_org", C.c_int32 * 3), ("drop_dims", C.c_int32 * 3)]
+                ("step_dev", C.c_void_p), ("drop_org", C.c_int32 * 3), ("drop_dims", C.c_int32 * 3),
+                ("keep_mask", C.c_void_p), ("keep_mode", C.c_int32)]
 
 
 class tem_conv_args(C.Structure):

@@ -322,6 +322,8 @@ int fill_dev(const tem_conv_args *a, ConvDev &p, bool transposed) {
     if (g.N != o0.N || g.D != o0.D || g.H != o0.H || g.W != o0.W || g.C < o0.C) return TEM_ESHAPE;
   }
   if (a->ep.add.ptr && (a->ep.add.C < o0.C || a->ep.add.N != o0.N)) return TEM_ESHAPE;
+  // keep_mode 1 (write the dropout keep mask) needs whole bytes per thread: C_out a multiple of 8
+  if (a->ep.dropout && a->ep.keep_mask && a->ep.keep_mode == 1 && o0.C % 8 != 0) return TEM_EUNSUPPORTED;
   return TEM_OK;
 }
 
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(256) void conv_generic_k(ConvDev p, int CI0, int CI
 }
 
 static int launch_generic(const ConvDev &p, const tem_conv_args *a, hipStream_t st, bool transposed) {
+  if (a->ep.dropout && a->ep.keep_mask && a->ep.keep_mode == 1) return TEM_EUNSUPPORTED;   // one channel per thread
   const int CI1 = a->in1.ptr ? a->in1.C : 0, CO1 = a->out1.ptr ? a->out1.C : 0;
   const int64_t cnt = p.total * (a->out0.C + CO1);
   if (cnt <= 0 || cnt > 0x7fffffffll * 256) return TEM_EUNSUPPORTED;

@@ -46,6 +46,7 @@ struct Ep32 {                    // epilogue with 32-bit strides
   DropoutStream ds;
   const uint32_t *step_dev;
   int32_t doz, doy, dox, dD, dH, dW;
+  const uint8_t *keep_mask;      // keep_mode 2: dropout bits drawn by the forward pass (else NULL)
 };
 
 struct Dev {
@@ -266,10 +267,16 @@ __global__ __launch_bounds__(NW * 64) void conv_lds_k(Dev p) {
             if (DROP && ep.dropout) {
               const uint64_t e = ((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) *
                                      (uint64_t)p.CO0 + tco;
-              const Philox128 ph = ds.block(e >> 7);
-              const uint32_t eb = (uint32_t)(e & 127);
+              if (ep.keep_mask) {                            // kernel-uniform: four bits of the forward pass's mask
+                const uint32_t bits = (uint32_t)ep.keep_mask[e >> 3] >> (uint32_t)(e & 4u);
 #pragma unroll
-              for (int c = 0; c < 4; ++c) v[c] = DropoutStream::bit(ph, eb + c) ? 2.f * v[c] : 0.f;
+                for (int c = 0; c < 4; ++c) v[c] = ((bits >> c) & 1u) ? 2.f * v[c] : 0.f;
+              } else {
+                const Philox128 ph = ds.block(e >> 7);
+                const uint32_t eb = (uint32_t)(e & 127);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = DropoutStream::bit(ph, eb + c) ? 2.f * v[c] : 0.f;
+              }
             }
             if (ep.slope != 1.f) {
 #pragma unroll
@@ -603,6 +610,8 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   q.dropout = e.dropout;
   q.ds.k0 = (uint32_t)e.seed; q.ds.k1 = (uint32_t)(e.seed >> 32); q.ds.site = e.site; q.ds.step = e.step;
   q.step_dev = e.step_dev;
+  if (e.dropout && e.keep_mask && e.keep_mode == 1) return TEM_EUNSUPPORTED;      // the direct kernels write the mask
+  q.keep_mask = (e.dropout && e.keep_mask && e.keep_mode == 2 && o0.C % 8 == 0) ? e.keep_mask : nullptr;
   q.doz = e.drop_org[0]; q.doy = e.drop_org[1]; q.dox = e.drop_org[2];
   q.dD = e.drop_dims[0] ? e.drop_dims[0] : o0.D; q.dH = e.drop_dims[0] ? e.drop_dims[1] : o0.H;
   q.dW = e.drop_dims[0] ? e.drop_dims[2] : o0.W;

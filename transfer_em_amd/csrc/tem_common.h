@@ -59,6 +59,8 @@ struct EpilogueDev {
   DropoutStream ds;
   const uint32_t *step_dev;
   int32_t doz, doy, dox, dD, dH, dW;     // dropout frame: origin of out0 inside the full tensor, full extents (dD == 0: none)
+  uint8_t *keep_mask;                    // tem_epilogue.keep_mask / keep_mode
+  int32_t keep_mode;
 };
 
 static inline EpilogueDev make_epilogue(const tem_epilogue &e) {
@@ -76,6 +78,7 @@ static inline EpilogueDev make_epilogue(const tem_epilogue &e) {
   d.step_dev = e.step_dev;
   d.doz = e.drop_org[0]; d.doy = e.drop_org[1]; d.dox = e.drop_org[2];
   d.dD = e.drop_dims[0]; d.dH = e.drop_dims[1]; d.dW = e.drop_dims[2];
+  d.keep_mask = e.keep_mask; d.keep_mode = e.keep_mask ? e.keep_mode : 0;
   return d;
 }
 
@@ -107,10 +110,28 @@ __device__ __forceinline__ void apply_epilogue(const EpilogueDev &ep, float (&v)
     if (ep.step_dev) ds.step = *ep.step_dev;
     uint64_t e = ep.dD ? ((((uint64_t)n * ep.dD + (z + ep.doz)) * ep.dH + (y + ep.doy)) * ep.dW + (x + ep.dox)) * (uint64_t)C + c0
                        : ((((uint64_t)n * D + z) * H + y) * W + x) * (uint64_t)C + c0;
-    Philox128 p = ds.block(e >> 7);
-    uint32_t eb = (uint32_t)(e & 127);
+    if (NC % 8 == 0 && ep.keep_mode == 2) {              // bits drawn by the forward pass
 #pragma unroll
-    for (int i = 0; i < NC; ++i) v[i] = DropoutStream::bit(p, eb + i) ? 2.f * v[i] : 0.f;
+      for (int b = 0; b < NC / 8; ++b) {
+        const uint32_t bits = ep.keep_mask[(e >> 3) + b];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[8 * b + i] = ((bits >> i) & 1u) ? 2.f * v[8 * b + i] : 0.f;
+      }
+    } else {
+      Philox128 p = ds.block(e >> 7);
+      uint32_t eb = (uint32_t)(e & 127);
+      if (NC % 8 == 0 && ep.keep_mode == 1) {
+#pragma unroll
+        for (int b = 0; b < NC / 8; ++b) {
+          uint32_t bits = 0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) bits |= (DropoutStream::bit(p, eb + 8 * b + i) ? 1u : 0u) << i;
+          ep.keep_mask[(e >> 3) + b] = (uint8_t)bits;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NC; ++i) v[i] = DropoutStream::bit(p, eb + i) ? 2.f * v[i] : 0.f;
+    }
   }
   if (ep.slope != 1.f) {
 #pragma unroll

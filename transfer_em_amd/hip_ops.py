@@ -84,7 +84,7 @@ def _p3(p, is3d):
 
 def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=None, layout=TEM_W_TAP_CI_CO,
                 transposed=False, slope=1.0, bias=None, gate=None, gate_slope=LEAKY, add=None, add_off=0,
-                dropout=None, drop_frame=None, direct=False):
+                dropout=None, drop_frame=None, keep_mask=None, direct=False):
     """Build a tem_conv / tem_conv_transpose launch.  `w` and `bias` are 1-D float32 tensors
     (slices of a network's flat parameter vector); dropout = (seed, site, step_dev_tensor)."""
     lib = _lib.load()
@@ -121,6 +121,11 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
             o3, d3 = _p3(org, is3d), _k3(full, is3d)
             for i in range(3):
                 ep.drop_org[i], ep.drop_dims[i] = o3[i], d3[i]
+        if keep_mask is not None:                 # (uint8 tensor over the dropout frame, mode): tem_epilogue.keep_mask
+            mask, mode = keep_mask
+            assert mask.dtype == torch.uint8 and mask.is_contiguous()
+            ep.keep_mask, ep.keep_mode = mask.data_ptr(), int(mode)
+            keep.append(mask)
     if transposed:
         fn = lib.tem_conv_transpose_direct if direct else lib.tem_conv_transpose
     else:

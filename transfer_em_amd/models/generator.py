@@ -146,6 +146,14 @@ class GenForward:
         self.skip1 = _window(A["d2a"], lo("u2b") + self.lo1 - lo("d2a"), size("u2b"), is3d)
         self.skip0 = _window(A["d1a"], lo("u1b") + self.lo0 - lo("d1a"), size("u1b"), is3d)
         dr = (lambda blk: (drop[0], dropout_site(drop[1], blk), drop[2])) if (training and drop) else (lambda blk: None)
+        # keep masks of the two Dropout layers (1 bit per element of the FULL tensors): written by the forward
+        # transposed convolutions, read by the matching input-gradient kernels instead of re-running Philox
+        self.keep = {}
+        if training and drop:
+            for blk, layer in ((0, "u2b"), (1, "u1b")):
+                vox = N * (e[layer] if is3d else 1) * e[layer] * e[layer]
+                self.keep[blk] = torch.zeros(vox * ch[layer] // 8, dtype=torch.uint8, device=x.device)
+        km = lambda blk, mode: (self.keep[blk], mode) if blk in self.keep else None
         kw = dict(is3d=is3d, direct=direct)
         pc = lambda p, s, i, o: p + lo(i) - s * lo(o) if i else p - s * lo(o)      # conv-like pad ('' = full input x)
         pt = lambda p, s, i, o: p + lo(o) - s * lo(i)                               # transposed-conv pad
@@ -158,12 +166,12 @@ class GenForward:
         L.append(cv("g.d2b", A["d2a"], P.w("d2b"), A["d2b"], 4, 2, pc(0, 2, "d2a", "d2b"), slope=H.LEAKY, **kw))
         L.append(cv("g.u2a", A["d2b"], P.w("u2a"), A["u2a"], 3, 1, pc(0, 1, "d2b", "u2a"), slope=H.LEAKY, **kw))
         L.append(cv("g.u2b", A["u2a"], P.w("u2b"), A["u2b"], 4, 2, pt(1, 2, "u2a", "u2b"), transposed=True,
-                    slope=H.LEAKY, dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]), **kw))
+                    slope=H.LEAKY, dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]), keep_mask=km(0, 1), **kw))
         L.append(cv("g.mid", A["u2b"], P.w("mid"), A["mid"], 3, 1, pc(0, 1, "u2b", "mid"), in1=self.skip1,
                     slope=H.LEAKY, **kw))
         L.append(cv("g.u1a", A["mid"], P.w("u1a"), A["u1a"], 3, 1, pc(0, 1, "mid", "u1a"), slope=H.LEAKY, **kw))
         L.append(cv("g.u1b", A["u1a"], P.w("u1b"), A["u1b"], 4, 2, pt(1, 2, "u1a", "u1b"), transposed=True,
-                    slope=H.LEAKY, dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), **kw))
+                    slope=H.LEAKY, dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), keep_mask=km(1, 1), **kw))
         L.append(cv("g.f1", A["u1b"], P.w("f1"), A["f1"], 3, 1, pc(0, 1, "u1b", "f1"), in1=self.skip0,
                     slope=H.LEAKY, **kw))
         L.append(cv("g.f2", A["f1"], P.w("f2"), A["f2"], 3, 1, pc(0, 1, "f1", "f2"), slope=1.0, **kw))
@@ -227,7 +235,8 @@ class GenBackward:
         L.append(cvb("g.bd.f2", dy, "f2", G["f1"], pc(2, 1, "f2", "f1"), gate=A["f1"], **kw))
         L.append(bww("f1", A["u1b"], G["f1"], 3, 1, pc(0, 1, "u1b", "f1"), in1=fwd.skip0))
         L.append(cvb("g.bd.f1", G["f1"], "f1", G["u1b"], pc(2, 1, "f1", "u1b"), out1=t_skip0,
-                    gate=A["u1b"], dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), **kw))
+                    gate=A["u1b"], dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]),
+                    keep_mask=(fwd.keep[1], 2) if 1 in fwd.keep else None, **kw))
         L.append(bww("u1b", G["u1b"], A["u1a"], 4, 2, pc(1, 2, "u1b", "u1a")))
         L.append(cv("g.bd.u1b", G["u1b"], P.w("u1b"), G["u1a"], 4, 2, pc(1, 2, "u1b", "u1a"), layout=AS,
                     gate=A["u1a"], **kw))
@@ -236,7 +245,8 @@ class GenBackward:
                     gate=A["mid"], **kw))
         L.append(bww("mid", A["u2b"], G["mid"], 3, 1, pc(0, 1, "u2b", "mid"), in1=fwd.skip1))
         L.append(cvb("g.bd.mid", G["mid"], "mid", G["u2b"], pc(2, 1, "mid", "u2b"), out1=t_skip1,
-                    gate=A["u2b"], dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]), **kw))
+                    gate=A["u2b"], dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]),
+                    keep_mask=(fwd.keep[0], 2) if 0 in fwd.keep else None, **kw))
         L.append(bww("u2b", G["u2b"], A["u2a"], 4, 2, pc(1, 2, "u2b", "u2a")))
         L.append(cv("g.bd.u2b", G["u2b"], P.w("u2b"), G["u2a"], 4, 2, pc(1, 2, "u2b", "u2a"), layout=AS,
                     gate=A["u2a"], **kw))
