@@ -189,11 +189,28 @@ def _keep(shape, training, drop, block):
     return ops.dropout_mask(shape, seed, dropout_site(call_id, block), step).astype(np.float32) * np.float32(2.0)
 
 
+def _gate_on(sv):
+    """LeakyReLU gradient gated on the saved output sv[key].  sv["gates"][key] (bool array, True = the
+    positive branch), when present, replaces the sign of the oracle's own activation: LeakyReLU' jumps at
+    0, so a pre-activation within rounding of 0 can take different branches in two float implementations
+    of the same forward.  The parity tests pass the gates of the implementation under test, so that both
+    sides differentiate the same branch everywhere and the comparison stays tight (tests/util.hip_gates)."""
+    gates = sv.get("gates") or {}
+
+    def gate(g, key, alpha=ops.LEAKY_ALPHA):
+        pos = gates.get(key)
+        if pos is None:
+            return ops.leaky_relu_grad_from_out(g, sv[key], alpha)
+        assert pos.shape == sv[key].shape, (key, pos.shape, sv[key].shape)
+        return np.where(pos, np.asarray(g, np.float32), np.float32(alpha) * np.asarray(g, np.float32)).astype(np.float32)
+    return gate
+
+
 def generator_backward(P, sv, dy, need_dx=False):
     """Hand-derived adjoint of generator_forward.  Returns (grads: name -> float64, dx or None)."""
     is3d = sv["is3d"]
     S, Pd = (lambda s: _stride(is3d, s)), (lambda p: _pad(is3d, p))
-    gate = ops.leaky_relu_grad_from_out
+    gate = _gate_on(sv)
     k3 = P["c0"].shape[:3]
     k4 = P["d1b"].shape[:3]
     G = OrderedDict()
@@ -201,33 +218,33 @@ def generator_backward(P, sv, dy, need_dx=False):
     c2n = P["u2b"].shape[3]
 
     G["f2"] = ops.conv_bwd_weight(sv["f1"], dy, k3, S(1), Pd(0))
-    g_f1 = gate(ops.conv_bwd_data(dy, P["f2"], sv["f1"].shape, S(1), Pd(0)), sv["f1"])
+    g_f1 = gate(ops.conv_bwd_data(dy, P["f2"], sv["f1"].shape, S(1), Pd(0)), "f1")
     G["f1"] = ops.conv_bwd_weight(sv["cat0"], g_f1, k3, S(1), Pd(0))
     g_cat0 = ops.conv_bwd_data(g_f1, P["f1"], sv["cat0"].shape, S(1), Pd(0))
-    g_c1 = gate(g_cat0[..., :c1n], sv["u1"]) * sv["k1"]
+    g_c1 = gate(g_cat0[..., :c1n], "u1") * sv["k1"]
     t_skip0 = g_cat0[..., c1n:]
     G["u1b"] = ops.convT_bwd_weight(sv["b1"], g_c1, k4, S(2), Pd(1))
-    g_b1 = gate(ops.convT_bwd_data(g_c1, P["u1b"], sv["b1"].shape, S(2), Pd(1)), sv["b1"])
+    g_b1 = gate(ops.convT_bwd_data(g_c1, P["u1b"], sv["b1"].shape, S(2), Pd(1)), "b1")
     G["u1a"] = ops.conv_bwd_weight(sv["m"], g_b1, k3, S(1), Pd(0))
-    g_m = gate(ops.conv_bwd_data(g_b1, P["u1a"], sv["m"].shape, S(1), Pd(0)), sv["m"])
+    g_m = gate(ops.conv_bwd_data(g_b1, P["u1a"], sv["m"].shape, S(1), Pd(0)), "m")
     G["mid"] = ops.conv_bwd_weight(sv["cat1"], g_m, k3, S(1), Pd(0))
     g_cat1 = ops.conv_bwd_data(g_m, P["mid"], sv["cat1"].shape, S(1), Pd(0))
-    g_c2 = gate(g_cat1[..., :c2n], sv["u2"]) * sv["k2"]
+    g_c2 = gate(g_cat1[..., :c2n], "u2") * sv["k2"]
     t_skip1 = g_cat1[..., c2n:]
     G["u2b"] = ops.convT_bwd_weight(sv["b2"], g_c2, k4, S(2), Pd(1))
-    g_b2 = gate(ops.convT_bwd_data(g_c2, P["u2b"], sv["b2"].shape, S(2), Pd(1)), sv["b2"])
+    g_b2 = gate(ops.convT_bwd_data(g_c2, P["u2b"], sv["b2"].shape, S(2), Pd(1)), "b2")
     G["u2a"] = ops.conv_bwd_weight(sv["d2"], g_b2, k3, S(1), Pd(0))
-    g_d2 = gate(ops.conv_bwd_data(g_b2, P["u2a"], sv["d2"].shape, S(1), Pd(0)), sv["d2"])
+    g_d2 = gate(ops.conv_bwd_data(g_b2, P["u2a"], sv["d2"].shape, S(1), Pd(0)), "d2")
     G["d2b"] = ops.conv_bwd_weight(sv["s1"], g_d2, k4, S(2), Pd(0))
     g_s1 = ops.conv_bwd_data(g_d2, P["d2b"], sv["s1"].shape, S(2), Pd(0))
-    g_s1 = gate(g_s1 + _embed(t_skip1, sv["s1"].shape, sv["lo1"], is3d), sv["s1"])
+    g_s1 = gate(g_s1 + _embed(t_skip1, sv["s1"].shape, sv["lo1"], is3d), "s1")
     G["d2a"] = ops.conv_bwd_weight(sv["d1"], g_s1, k3, S(1), Pd(0))
-    g_d1 = gate(ops.conv_bwd_data(g_s1, P["d2a"], sv["d1"].shape, S(1), Pd(0)), sv["d1"])
+    g_d1 = gate(ops.conv_bwd_data(g_s1, P["d2a"], sv["d1"].shape, S(1), Pd(0)), "d1")
     G["d1b"] = ops.conv_bwd_weight(sv["s0"], g_d1, k4, S(2), Pd(0))
     g_s0 = ops.conv_bwd_data(g_d1, P["d1b"], sv["s0"].shape, S(2), Pd(0))
-    g_s0 = gate(g_s0 + _embed(t_skip0, sv["s0"].shape, sv["lo0"], is3d), sv["s0"])
+    g_s0 = gate(g_s0 + _embed(t_skip0, sv["s0"].shape, sv["lo0"], is3d), "s0")
     G["d1a"] = ops.conv_bwd_weight(sv["a0"], g_s0, k3, S(1), Pd(0))
-    g_a0 = gate(ops.conv_bwd_data(g_s0, P["d1a"], sv["a0"].shape, S(1), Pd(0)), sv["a0"])
+    g_a0 = gate(ops.conv_bwd_data(g_s0, P["d1a"], sv["a0"].shape, S(1), Pd(0)), "a0")
     G["c0"] = ops.conv_bwd_weight(sv["x"], g_a0, k3, S(1), Pd(sv["in_pad"]))
     dx = None
     if need_dx:
@@ -297,15 +314,12 @@ def discriminator_forward(P, x, is3d=True, prior=None):
     return z, sv
 
 
-def _gate2(g, y):
-    """Adjoint of lrelu(lrelu(.)) gated on the final output."""
-    return np.where(y > 0, g, DOUBLE_LEAKY * g).astype(np.float32)
 
 
 def discriminator_backward(P, sv, dz, need_dx=False, need_dw=True):
     is3d = sv["is3d"]
     S, Pd = (lambda s: _stride(is3d, s)), (lambda p: _pad(is3d, p))
-    gate = ops.leaky_relu_grad_from_out
+    gate = _gate_on(sv)
     k3, k4, k1 = P["d2a"].shape[:3], P["d2b"].shape[:3], (1, 1, 1)
     G = OrderedDict()
 
@@ -316,29 +330,29 @@ def discriminator_backward(P, sv, dz, need_dx=False, need_dw=True):
     bw("p2", sv["p1"], dz, k1, 1)
     if need_dw:
         G["p2_bias"] = np.asarray(dz, np.float64).sum(axis=(0, 1, 2, 3))
-    g_p1 = gate(ops.conv_bwd_data(dz, P["p2"], sv["p1"].shape, S(1), Pd(0)), sv["p1"])
+    g_p1 = gate(ops.conv_bwd_data(dz, P["p2"], sv["p1"].shape, S(1), Pd(0)), "p1")
     bw("p1", sv["e6"], g_p1, k1, 1)
-    g_e6 = _gate2(ops.conv_bwd_data(g_p1, P["p1"], sv["e6"].shape, S(1), Pd(0)), sv["e6"])
+    g_e6 = gate(ops.conv_bwd_data(g_p1, P["p1"], sv["e6"].shape, S(1), Pd(0)), "e6", DOUBLE_LEAKY)  # adjoint of lrelu(lrelu(.)) gated on the final output
     bw("d3b", sv["e5"], g_e6, k4, 2)
-    g_e5 = gate(ops.conv_bwd_data(g_e6, P["d3b"], sv["e5"].shape, S(2), Pd(0)), sv["e5"])
+    g_e5 = gate(ops.conv_bwd_data(g_e6, P["d3b"], sv["e5"].shape, S(2), Pd(0)), "e5")
     bw("d3a", sv["cat"], g_e5, k3, 1)
     g_cat = ops.conv_bwd_data(g_e5, P["d3a"], sv["cat"].shape, S(1), Pd(0))
     c4 = sv["e4"].shape[-1]
-    g_e4 = gate(g_cat[..., :c4], sv["e4"])
+    g_e4 = gate(g_cat[..., :c4], "e4")
     dx_prior = None
     if sv.get("prior") is not None and need_dx:
         dx_prior = prior_backward_data(sv["prior"], sv["pacts"], sv["x"].shape,
                                        np.ascontiguousarray(g_cat[..., c4:]), is3d)
     bw("d2b", sv["e3"], g_e4, k4, 2)
-    g_e3 = gate(ops.conv_bwd_data(g_e4, P["d2b"], sv["e3"].shape, S(2), Pd(0)), sv["e3"])
+    g_e3 = gate(ops.conv_bwd_data(g_e4, P["d2b"], sv["e3"].shape, S(2), Pd(0)), "e3")
     bw("d2a", sv["h"], g_e3, k3, 1)
-    g_h = gate(ops.conv_bwd_data(g_e3, P["d2a"], sv["h"].shape, S(1), Pd(0)), sv["h"])
+    g_h = gate(ops.conv_bwd_data(g_e3, P["d2a"], sv["h"].shape, S(1), Pd(0)), "h")
     dx = None
     if is3d:
         bw("hack", sv["e2"], g_h, k3, 1)
-        g_e2 = gate(ops.conv_bwd_data(g_h, P["hack"], sv["e2"].shape, S(1), Pd(0)), sv["e2"])
+        g_e2 = gate(ops.conv_bwd_data(g_h, P["hack"], sv["e2"].shape, S(1), Pd(0)), "e2")
         bw("d1b", sv["e1"], g_e2, k4, 2)
-        g_e1 = gate(ops.conv_bwd_data(g_e2, P["d1b"], sv["e1"].shape, S(2), Pd(0)), sv["e1"])
+        g_e1 = gate(ops.conv_bwd_data(g_e2, P["d1b"], sv["e1"].shape, S(2), Pd(0)), "e1")
         bw("d1a", sv["x"], g_e1, k3, 1)
         if need_dx:
             dx = ops.conv_bwd_data(g_e1, P["d1a"], sv["x"].shape, S(1), Pd(0))
@@ -388,11 +402,13 @@ def unflatten(vec, like):
 
 
 def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, seed=42, step=0, prior_y=None,
-                     training=True):
+                     training=True, gates=None):
     """Forward + losses + the four gradient sets of EM2EM.train_step (cgan.py:144-215).
 
     Uses the exact 2-sweep reformulation: the generators see
     S = gen_g + gen_f + total_cycle + id_x + id_y, the discriminators their own loss.
+    gates: optional callable(saved) -> {call: {saved key: bool array}} evaluated after the forward passes;
+    the backward passes then take every listed LeakyReLU branch from it (see _gate_on).
     Returns (losses7: float64[7] in the reference's return order, grads dict, aux)."""
     n = real_x.shape[3]
     out = generator_out(n)
@@ -415,6 +431,12 @@ def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, see
     z_ry, sv_dyr = discriminator_forward(Pdy, y_c, is3d, prior_y)       # only discriminator_y gets disc_prior (cgan.py:59)
     z_fx, sv_dxf = discriminator_forward(Pdx, fake_x, is3d)
     z_fy, sv_dyf = discriminator_forward(Pdy, fake_y, is3d, prior_y)
+
+    saved = dict(g1=sv_g1, f2=sv_f2, f1=sv_f1, g2=sv_g2, f3=sv_f3, g3=sv_g3,
+                 dxr=sv_dxr, dyr=sv_dyr, dxf=sv_dxf, dyf=sv_dyf)
+    if gates is not None:
+        for call, g in gates(saved).items():
+            saved[call]["gates"] = g
 
     gen_g, dz_gen_g = generator_loss(z_fy, gamma)
     gen_f, dz_gen_f = generator_loss(z_fx, gamma)
@@ -456,18 +478,22 @@ def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, see
     aux = dict(fake_y=fake_y, fake_x=fake_x, cyc_x=cyc_x, cyc_y=cyc_y, same_x=same_x, same_y=same_y,
                z_rx=z_rx, z_ry=z_ry, z_fx=z_fx, z_fy=z_fy, sv_g1=sv_g1, buffer=b,
                d_fake_y=d_fake_y, d_fake_x=d_fake_x,
-               saved=dict(g1=sv_g1, f2=sv_f2, f1=sv_f1, g2=sv_g2, f3=sv_f3, g3=sv_g3,
-                          dxr=sv_dxr, dyr=sv_dyr, dxf=sv_dxf, dyf=sv_dyf))
+               saved=saved)
     return losses, dict(g=grad_g, f=grad_f, dx=grad_dx, dy=grad_dy), aux
 
 
-def train_step(state, real_x, real_y, is3d=True, gamma=2.0, seed=42, prior_y=None):
+def train_step(state, real_x, real_y, is3d=True, gamma=2.0, seed=42, prior_y=None, gates=None, grad_mean_with=None):
     """Full EM2EM.train_step incl. the four simultaneous Keras-Adam updates (cgan.py:218-228).
 
     state: dict with params 'g','f','dx','dy' (OrderedDicts), adam 'm','v' per net (same
     structure, zeros initially) and integer 'step' (number of updates already applied)."""
     losses, grads, aux = train_step_grads(state["g"], state["f"], state["dx"], state["dy"],
-                                          real_x, real_y, is3d, gamma, seed, state["step"], prior_y=prior_y)
+                                          real_x, real_y, is3d, gamma, seed, state["step"], prior_y=prior_y,
+                                          gates=gates)
+    if grad_mean_with is not None:
+        # data parallelism (the MirroredStrategy TODO, cgan.py:8-11): callable(grads) -> grads averaged over
+        # the replicas; every replica then applies the same update
+        grads = grad_mean_with(grads)
     t = state["step"] + 1
     for net in ("g", "f", "dx", "dy"):
         for k in state[net]:

@@ -34,7 +34,10 @@ def _worker(rank, world, port, out):
     mine = D.shard(range(world), rank, world)                       # one volume per replica
     _, grads, _ = graph.train_step_grads(*P, X[mine], Y[mine], False, training=False)
     flat = torch.from_numpy(np.concatenate([graph.flatten(grads[k]) for k in ("g", "f", "dx", "dy")]))
-    D.mean_gradient_(flat)                                          # the collective under test
+    # the exchange the product runs (cgan._allreduce_bucket): SUM over replicas, 1/world applied afterwards
+    # (the HIP path folds it into tem_adam_keras's grad_scale)
+    D.allreduce_sum_(flat)
+    flat /= world
     if rank == 0:
         _, gfull, _ = graph.train_step_grads(*P, X, Y, False, training=False)
         ref = np.concatenate([graph.flatten(gfull[k]) for k in ("g", "f", "dx", "dy")])

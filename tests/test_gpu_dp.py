@@ -1,0 +1,88 @@
+"""The product's data-parallel train step, two replicas (the MirroredStrategy the reference lists as TODO,
+cgan.py:8-11,55-57): EM2EM with a process group runs the bucketed gradient exchange on the step's streams,
+`grad_scale = 1/world` inside the Adam kernel, the parameter broadcast at construction, one dropout stream per
+replica and rank-0-only checkpoints.  Both ranks share the one card of the GPU box and talk over gloo (RCCL wants
+one GPU per rank; the driver's 8-GPU run covers that transport) -- every line of the product's DP path is the same.
+
+Checked against the oracle: per-replica gradients (dropout seed + rank) averaged, then ONE Keras-Adam update."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from util import scaled_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_dp(is3d, steps=2, world=2):
+    from oracle import graph, ops
+    n = 74
+    gs, ds = graph.generator_param_shapes(is3d), graph.discriminator_param_shapes(is3d)
+    st = graph.new_state(is3d)
+    st["g"], st["f"], st["dx"], st["dy"] = (scaled_params(gs, 10), scaled_params(gs, 11), scaled_params(ds, 12),
+                                              scaled_params(ds, 13))
+    shape = (1, n if is3d else 1, n, n, 1)
+    data = []
+    for r in range(world):
+        rng = np.random.default_rng(1000 + r)
+        data.append((rng.standard_normal(shape).astype(np.float32), rng.standard_normal(shape).astype(np.float32)))
+    losses, grads_mean = [], None
+    for _ in range(steps):
+        per_rank = [graph.train_step_grads(st["g"], st["f"], st["dx"], st["dy"], x, y, is3d, 2.0, 42 + r, st["step"])
+                    for r, (x, y) in enumerate(data)]
+        losses.append([p[0] for p in per_rank])
+        grads_mean = {net: {k: sum(np.asarray(p[1][net][k], np.float64) for p in per_rank) / world
+                            for k in st[net]} for net in ("g", "f", "dx", "dy")}
+        t = st["step"] + 1
+        for net in ("g", "f", "dx", "dy"):
+            for k in st[net]:
+                st[net][k], st["m"][net][k], st["v"][net][k] = ops.adam_keras(
+                    st[net][k], grads_mean[net][k], st["m"][net][k], st["v"][net][k], t)
+        st["step"] = t
+    return st, np.asarray(losses), grads_mean
+
+
+def _flat(d):
+    return np.concatenate([np.asarray(v, np.float64).ravel() for v in d.values()])
+
+
+@pytest.mark.parametrize("is3d", [False])
+def test_two_rank_step_matches_oracle(tmp_path, rank_launcher, oracle_lib, is3d):
+    res = rank_launcher([sys.executable, os.path.join(ROOT, "tests", "tools", "dp_rank.py"), str(tmp_path)] +
+                        (["3d"] if is3d else []), ranks=2, timeout=900)
+    assert res["rc"] == [0, 0], "\n".join(res["tail"])
+    r0, r1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2))
+    # construction: different seeds -> different weights; the broadcast made them rank 0's (tested again below
+    # through the loaded start state); replicas draw different dropout streams
+    assert not np.array_equal(r0["init"][:1000], np.zeros(1000)) and np.array_equal(r0["init"], r1["init"])
+    assert int(r0["seed"]) == 42 and int(r1["seed"]) == 43
+    assert int(r0["step"][0]) == 2 and int(r1["step"][0]) == 2
+    # the exchange: both replicas hold the same summed gradient and bit-identical parameters / moments
+    assert np.array_equal(r0["grad_all"], r1["grad_all"])
+    for key in ("g", "f", "dx", "dy"):
+        for which in ("theta", "m", "v"):
+            assert np.array_equal(r0[f"{key}.{which}"], r1[f"{key}.{which}"]), (key, which)
+    # rank-0-only checkpoint (cgan.py:105-107 under data parallelism)
+    assert str(r0["ckpt"]).endswith("ckpt-1.pt") and os.path.isfile(str(r0["ckpt"])) and str(r1["ckpt"]) == ""
+    assert not os.path.exists(os.path.join(tmp_path, "ckpt1", "train_dp"))
+    # against the oracle: local losses per replica, mean gradient (grad_all is the SUM: grad_scale = 1/2 lives in
+    # the Adam kernel), moments and parameters after two updates
+    st, losses, gmean = _oracle_dp(is3d)
+    for r, rec in enumerate((r0, r1)):
+        assert np.abs(rec["losses"] - losses[:, r]).max() <= 1e-5 * np.abs(losses).max(), r
+    gref = np.concatenate([_flat(gmean[k]) for k in ("g", "f", "dx", "dy")])
+    o = 0
+    for key in ("g", "f", "dx", "dy"):
+        nk = _flat(gmean[key]).size
+        ref, got = gref[o:o + nk], r0["grad_all"][o:o + nk] / 2.0
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 3e-8, key
+        for which, tol in (("m", 1e-4), ("v", 2e-4)):
+            want = _flat(st[which][key])
+            assert np.abs(r0[f"{key}.{which}"] - want).max() <= tol * np.abs(want).max() + 1e-13, (key, which)
+        th, want = r0[f"{key}.theta"], _flat(st[key])
+        big = np.abs(ref) >= 1e-2 * np.abs(ref).max()
+        assert np.abs(th - want)[big].max() < 0.15 * 2e-4 and np.abs(th - want).max() <= 2 * 2.05 * 2e-4, key
+        o += nk

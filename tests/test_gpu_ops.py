@@ -290,6 +290,18 @@ def test_losses_and_adam(H, oracle_lib):
         H.run([H.adam_launch("adam", dth, dg, dm, dv, step), H.step_tick_launch(step)])
     assert rel_err(dth.cpu().numpy(), th) < 1e-6 and rel_err(dv.cpu().numpy(), v) < 1e-6
     assert int(step.item()) == 3
+    # grad_scale (data parallelism: the all-reduce delivers the SUM over replicas, the kernel applies 1/world):
+    # same result as the oracle fed the scaled gradient
+    for scale in (0.5, 1.0 / 3.0):
+        th2, g2 = rnd(rng, 777), rnd(rng, 777)
+        m2, v2 = np.zeros(777, np.float32), np.zeros(777, np.float32)
+        d2 = [dev(a) for a in (th2, g2, m2, v2)]
+        step.zero_()
+        for t in range(1, 3):
+            th2, m2, v2 = oracle_lib.adam_keras(th2, (np.float32(scale) * g2).astype(np.float32), m2, v2, t)
+            H.run([H.adam_launch("adam", d2[0], d2[1], d2[2], d2[3], step, grad_scale=scale), H.step_tick_launch(step)])
+        assert rel_err(d2[0].cpu().numpy(), th2) < 1e-6 and rel_err(d2[2].cpu().numpy(), m2) < 1e-6
+        assert rel_err(d2[3].cpu().numpy(), v2) < 1e-6
 
 
 def test_uint8_boundaries(H, oracle_lib):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import gate_flips, rel_err, scaled_params
+from util import gate_flips, hip_gates, rel_err, scaled_params
 
 pytestmark = pytest.mark.gpu
 
@@ -54,7 +54,9 @@ def test_train_step_matches_oracle(tmp_path, oracle_lib, is3d, batch, scaled):
         cs = model._steps[batch]
         grads_hip = {k: net.params.to_dict("grad") for k, net in
                      zip(("g", "f", "dx", "dy"), model._nets)}
-        losses, grads, aux = graph.train_step(st, rx, ry, is3d, 2.0, 42)
+        # the oracle's backward takes every LeakyReLU branch from the HIP forward (util.hip_gates): both sides
+        # differentiate the same piecewise-linear function, so the gradient bar below is unconditional
+        losses, grads, aux = graph.train_step(st, rx, ry, is3d, 2.0, 42, gates=hip_gates(cs, is3d))
         assert rel_err(got, losses) < 1e-5, (got, losses)
         b = model.buffer
         crop = (lambda t: t[:, b:-b, b:-b, b:-b, :]) if is3d else (lambda t: t[:, :, b:-b, b:-b, :])
@@ -62,10 +64,9 @@ def test_train_step_matches_oracle(tmp_path, oracle_lib, is3d, batch, scaled):
                           ("same_y", "g3")):
             ref = crop(aux[key]) if key.startswith("cyc") else aux[key]      # cycled_*: only the cropped window exists
             assert rel_err(cs.fwd[plan].y.cpu().numpy(), ref) < 1e-4, key
-        # gradients: tight when no LeakyReLU gate differs between the two forwards, see util.gate_flips
-        flips = gate_flips(cs, aux["saved"], is3d)
-        gtol = 1e-2 if flips else (2e-4 if is3d else 1e-4)
-        print(f"step {step}: {flips} gate flips, gradient tolerance {gtol:g}")
+        flips = gate_flips(cs, aux["saved"], is3d)          # diagnostic only (pre-activations within rounding of 0)
+        gtol = 2e-4 if is3d else 1e-4
+        print(f"step {step}: {flips} gate flips (aligned), gradient tolerance {gtol:g}")
         assert rel_err(cs.bwd["f2"].dx.cpu().numpy(), aux["d_fake_y"]) < gtol
         for net in ("g", "f", "dx", "dy"):
             for name, ref in grads[net].items():
@@ -107,14 +108,15 @@ def test_train_step_3d_batch2_one_step(tmp_path, oracle_lib):
     _load(model, st)
     got = model.train_step(torch.from_numpy(rx), torch.from_numpy(ry)).cpu().numpy()
     grads_hip = {k: net.params.to_dict("grad") for k, net in zip(("g", "f", "dx", "dy"), model._nets)}
-    losses, grads, aux = graph.train_step_grads(st["g"], st["f"], st["dx"], st["dy"], rx, ry, True, 2.0, 42, 0)
-    assert rel_err(got, losses) < 1e-5
     cs = model._steps[2]
+    losses, grads, aux = graph.train_step_grads(st["g"], st["f"], st["dx"], st["dy"], rx, ry, True, 2.0, 42, 0,
+                                                gates=hip_gates(cs, True))
+    assert rel_err(got, losses) < 1e-5
     for key, plan in (("fake_y", "g1"), ("fake_x", "f1"), ("same_x", "f3"), ("same_y", "g3")):
         assert rel_err(cs.fwd[plan].y.cpu().numpy(), aux[key]) < 1e-4, key
     flips = gate_flips(cs, aux["saved"], True)
-    gtol = 1e-2 if flips else 2e-4
-    print(f"{flips} gate flips, gradient tolerance {gtol:g}")
+    gtol = 2e-4                                             # unconditional: the oracle backward uses the HIP gates
+    print(f"{flips} gate flips (aligned), gradient tolerance {gtol:g}")
     for net in ("g", "f", "dx", "dy"):
         scale = max(np.abs(v).max() for v in grads[net].values())
         for name, ref in grads[net].items():

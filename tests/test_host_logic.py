@@ -43,6 +43,58 @@ def test_dataset_pipeline():
     assert len(dsg) == 3 and next(iter(dsg)).shape == (1, 8, 8, 8, 1)
 
 
+def test_generator_dataset_streams_fresh_samples_each_epoch():
+    """datasets.py:69-119: no caching -- every epoch takes `epoch_size` NEW samples from the generator."""
+    from transfer_em_amd.datasets import datasets as D
+
+    def counting():
+        i = 0
+        while True:
+            yield np.full((4, 4), i % 256, np.uint8)
+            i += 1
+    ds, ms = D.create_dataset_from_generator(counting(), batch_size=2, epoch_size=6, global_adjust=False)
+    assert len(ds) == 3 and ms is None
+    raw = lambda b: np.rint((np.asarray(b)[:, 0, 0, 0] + 1) * 127.5).astype(int).tolist()
+    e1 = [raw(b) for b in ds]
+    e2 = [raw(b) for b in ds]
+    assert e1 == [[0, 1], [2, 3], [4, 5]] and e2 == [[6, 7], [8, 9], [10, 11]]
+    # statistics pass: bounded, and its samples open epoch 1 instead of being thrown away
+    ramp = (np.arange(16, dtype=np.uint8).reshape(4, 4) + t for t in counting())     # non-constant samples
+    ds2, ms2 = D.create_dataset_from_generator(ramp, batch_size=1, epoch_size=4)
+    assert ms2 is not None and np.isfinite(ms2).all()
+    first = [float(np.asarray(b).mean()) for b in ds2]
+    assert len(first) == 4 and first == sorted(first) and len(set(first)) == 4        # samples 0..3, each once
+    # data-parallel replicas: interleaved batches of a tensor dataset, equal step counts
+    imgs = [np.full((4, 4), i, np.uint8) for i in range(9)]
+    parts = []
+    for r in range(2):
+        d, _ = D.create_dataset_from_tensors(imgs, batch_size=2, enable_augmentation=False, global_adjust=False,
+                                             rank=r, world_size=2)
+        parts.append([raw(b) for b in d])
+    assert parts == [[[0, 1], [4, 5]], [[2, 3], [6, 7]]]
+
+
+def test_oracle_backward_gate_override():
+    """oracle.graph: `gates` replaces the LeakyReLU branch the backward differentiates (tests/util.hip_gates feeds
+    it the HIP forward's signs).  The oracle's own signs reproduce the plain result bit for bit; a flipped gate
+    scales exactly that element's gradient."""
+    from oracle import graph, ops
+    rng = np.random.default_rng(0)
+    P = graph.init_params(graph.discriminator_param_shapes(False), 1)
+    for k in P:
+        P[k] = (P[k] * 30).astype(np.float32)
+    x = rng.standard_normal((1, 1, 40, 40, 1)).astype(np.float32)
+    z, sv = graph.discriminator_forward(P, x, False)
+    dz = rng.standard_normal(z.shape).astype(np.float32)
+    g0, dx0 = graph.discriminator_backward(P, sv, dz, need_dx=True)
+    sv["gates"] = {k: sv[k] > 0 for k in ("h", "e3", "e4", "e5", "e6", "p1")}
+    g1, dx1 = graph.discriminator_backward(P, sv, dz, need_dx=True)
+    assert np.array_equal(dx0, dx1) and all(np.array_equal(g0[k], g1[k]) for k in g0)
+    sv["gates"]["p1"] = ~sv["gates"]["p1"]
+    g2, _ = graph.discriminator_backward(P, sv, dz, need_dx=True)
+    assert not np.array_equal(g0["p1"], g2["p1"]) and np.array_equal(g0["p2"], g2["p2"])
+
+
 def test_tile_plan_matches_reference_logic():
     from transfer_em_amd.utils import tile_plan
     # dimsize 132: out 96, buffer 18, 96 % 6 == 0 -> no tpad; 260^3 request -> 27 tiles (SURVEY 3.5)

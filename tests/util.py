@@ -62,6 +62,41 @@ def gate_flips(cs, saved, is3d=True):
     return n
 
 
+def hip_gates(cs, is3d=True):
+    """`gates` argument of oracle.graph.train_step(_grads): the LeakyReLU branches of the HIP forward.
+
+    For every saved activation of the oracle the sign pattern is taken from the HIP path's own activation
+    buffer (cs.fwd[call].act[layer]); the cycle-path call sites hold only the region R[layer] of each tensor
+    (models/generator.needed_regions) -- outside it the oracle's own signs stay (every gradient is exactly
+    zero there).  With this the oracle differentiates the very branch the HIP backward gates on, and the
+    step-level gradient comparison needs no widened tolerance; gate_flips() stays a printed diagnostic."""
+    def build(saved):
+        out = {}
+        for call, sv in saved.items():
+            fwd = cs.fwd[call]
+            gen = call[0] in "gf"
+            table = _GEN_SAVED if gen else _DISC_SAVED
+            g = {}
+            for layer, key in table.items():
+                if key not in sv or layer not in fwd.act:
+                    continue
+                pos = np.asarray(sv[key]) > 0
+                got = fwd.act[layer].cpu().numpy() > 0
+                if gen:
+                    lo, hi = fwd.regions[layer]
+                    if is3d:
+                        pos[:, lo:hi, lo:hi, lo:hi, :] = got
+                    else:
+                        pos[:, :, lo:hi, lo:hi, :] = got
+                else:
+                    assert pos.shape == got.shape
+                    pos = got
+                g[key] = pos
+            out[call] = g
+        return out
+    return build
+
+
 def prior_layers(is3d, seed=5, extra_tail=True):
     """A frozen prior in the layer-list form of transfer_em_amd.models.prior (shaped like the
     discriminator trunk up to Downsample_2 so that its output matches, discriminator.py:62-66).

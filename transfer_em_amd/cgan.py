@@ -156,18 +156,32 @@ class _CompiledStep:
         third += [("wait", "adv"), ("wait", "d_fake_x"), add_x] + L_(b_f1) + red["f"] + [("record", "third_done")]
         main += [("wait", "side_done"), ("wait", "third_done")]
         self.lists = (main, side, third)
-        self.extra_streams = tuple(torch.cuda.Stream(device=dev) for _ in range(len(self.lists) - 1))
-        names = {"inputs", "joined"} | {it[1] for l in self.lists for it in l if isinstance(it, tuple)}
-        self.events = {k: torch.cuda.Event() for k in names}
-        self._hops = []
 
         # ---- optimizer (cgan.py:218-228); gradients are averaged over ranks by grad_scale
         ws = m.world_size
         P = lambda net: net.params
-        self.update = [H.adam_launch("adam." + nm, P(net).theta, P(net).grad, P(net).m, P(net).v, m.step_dev,
-                                     grad_scale=1.0 / ws)
-                       for nm, net in (("g", G), ("f", F), ("dx", DX), ("dy", DY))]
-        self.update.append(H.step_tick_launch(m.step_dev))
+        adam = {nm: H.adam_launch("adam." + nm, P(net).theta, P(net).grad, P(net).m, P(net).v, m.step_dev,
+                                  grad_scale=1.0 / ws)
+                for nm, net in (("g", G), ("f", F), ("dx", DX), ("dy", DY))}
+        tick = H.step_tick_launch(m.step_dev)
+        self.update = [adam["g"], adam["f"], adam["dx"], adam["dy"], tick]
+
+        # ---- the same schedule with the exchange step and the optimizer INSIDE the stream lists (default path).
+        # Data parallelism has one exchange per step; it is issued as two buckets so that neither
+        # sits on the critical path: the discriminators' gradients leave on the side stream as soon as their slab
+        # reduction is enqueued (the generator sweep still has most of its work ahead), the generators' after the
+        # generator sweep; each bucket's Adam launches follow their collective on the same stream.  ("allreduce",
+        # key) is a no-op for world_size 1, so single-GPU runs execute the identical kernel sequence.
+        cut = lambda lst, name: lst[:next(i for i, it in enumerate(lst) if it == ("record", name))]
+        side_f = cut(side, "side_done") + [("allreduce", "d"), adam["dx"], adam["dy"], ("record", "side_done")]
+        third_f = list(third)
+        main_f = main[:-2] + [("wait", "third_done"), ("allreduce", "g"), adam["g"], adam["f"], ("wait", "side_done"), tick]
+        self.lists_fused = (main_f, side_f, third_f)
+        self.extra_streams = tuple(torch.cuda.Stream(device=dev) for _ in range(len(self.lists) - 1))
+        names = {"inputs", "joined"} | {it[1] for l in self.lists for it in l if isinstance(it, tuple) and it[0] != "allreduce"}
+        self.events = {k: torch.cuda.Event() for k in names}
+        self._hops = []
+
         self.graphs, self.warm = None, False
 
 
@@ -234,6 +248,8 @@ class EM2EM(object):
         for n in self._nets:
             n.params.grad = self.grad_all[o:o + n.params.count]
             o += n.params.count
+        ngen = self.generator_g.params.count + self.generator_f.params.count
+        self.grad_buckets = {"g": self.grad_all[:ngen], "d": self.grad_all[ngen:]}   # exchange buckets (see _CompiledStep)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # Adam t-1 / dropout step
         self._steps = {}
 
@@ -287,6 +303,13 @@ class EM2EM(object):
         return path
 
     def _restore(self, path):
+        """`path`: a checkpoint file, or the reference-style prefix '.../ckpt-N' (tf.train.Checkpoint.restore takes
+        the prefix without extension, cgan.py:98-100; the file here is '<prefix>.pt')."""
+        if not os.path.isfile(path):
+            if os.path.isfile(path + ".pt"):
+                path = path + ".pt"
+            else:
+                raise FileNotFoundError(f"checkpoint not found: neither {path!r} nor {path + '.pt'!r} exists")
         state = torch.load(path, map_location="cpu", weights_only=True)
         for nm, n in zip(("generator_g", "generator_f", "discriminator_x", "discriminator_y"), self._nets):
             for k, t in n.params.state().items():
@@ -309,11 +332,24 @@ class EM2EM(object):
         real_x = self._as_input(real_x)
         real_y = self._as_input(real_y)
         st = self._compiled(real_x.shape[0])
+        for name, t in (("real_x", real_x), ("real_y", real_y)):
+            if tuple(t.shape) != tuple(st.real_x.shape):          # copy_ would silently broadcast
+                raise ValueError(f"train_step: {name} has shape {tuple(t.shape)}, this model takes "
+                                 f"{tuple(st.real_x.shape)} (batch, {'D, ' if self.is3d else '1, '}H, W, 1)")
         st.real_x.copy_(real_x, non_blocking=True)
         st.real_y.copy_(real_y, non_blocking=True)
         return self._run_step(st)
 
-    def _run_streams(self, st, trace=None, hop=False):
+    def _allreduce_bucket(self, key, stream):
+        """Sum one gradient bucket over the replicas on `stream` (RCCL over xGMI; the Adam kernel scales by 1/world).
+        The collective is enqueued behind the work already on `stream` and the bucket's Adam launches behind it;
+        the other streams keep computing meanwhile."""
+        if self.world_size == 1:
+            return
+        with torch.cuda.stream(stream):
+            D.allreduce_sum_(self.grad_buckets[key], self.pg)
+
+    def _run_streams(self, st, trace=None, hop=False, lists=None):
         """Enqueue the step's launch lists on their streams.  `trace` (bench.py): list receiving
         (launch, start_event, end_event) with the events recorded on the launch's own stream.
         Host-side order: a list runs until it needs an event no list has recorded yet, then the
@@ -327,7 +363,7 @@ class EM2EM(object):
         st.events["inputs"].record(cur)              # losses cleared + inputs copied
         streams = [cur] + list(st.extra_streams)
         used = [True] + [False] * (len(streams) - 1)
-        its = [iter(l) for l in st.lists]
+        its = [iter(l) for l in (st.lists if lists is None else lists)]
         pending = [None] * len(its)
         done = [False] * len(its)
         recorded = {"inputs"}
@@ -357,7 +393,9 @@ class EM2EM(object):
                     stream = streams[i]
                     if isinstance(item, tuple):
                         kind, name = item
-                        if kind == "record":
+                        if kind == "allreduce":
+                            self._allreduce_bucket(name, stream)
+                        elif kind == "record":
                             st.events[name].record(stream); recorded.add(name)
                         elif name in recorded:
                             wait(i, name)
@@ -380,17 +418,29 @@ class EM2EM(object):
             st.events["joined"].record(streams[0]); cur.wait_event(st.events["joined"])
 
     def _compute(self, st):
+        """Gradients of all four networks into grad_all (no exchange, no update)."""
         st.losses.zero_()
         if self.two_streams:
             self._run_streams(st, hop=torch.cuda.is_current_stream_capturing())
         else:
             H.run(st.compute, H.current_stream())
 
+    def _step_fused(self, st):
+        """The whole step -- gradients, bucketed exchange (N > 1), the four Adam updates -- on the three streams."""
+        st.losses.zero_()
+        self._run_streams(st, hop=torch.cuda.is_current_stream_capturing(), lists=st.lists_fused)
+
     def _capture(self, st):
-        """Capture the gradient computation (all three streams) and the optimizer update as two HIP
-        graphs; the data-parallel all-reduce, when there is one, runs between them."""
+        """Capture the step as HIP graphs.  One replica: the fused three-stream step is one graph.  Data parallel:
+        the gradient computation and the optimizer update are two graphs with the all-reduce between them."""
         torch.cuda.synchronize(self.device)
         pool = torch.cuda.graph_pool_handle()
+        if self.world_size == 1 and self.two_streams:
+            g_step = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_step, pool=pool):
+                self._step_fused(st)
+            st.graphs = (g_step,)
+            return
         g_compute, g_update = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_compute, pool=pool):
             self._compute(st)
@@ -405,14 +455,18 @@ class EM2EM(object):
                 self._capture(st)
             if st.graphs is not None:
                 st.graphs[0].replay()
-                if self.world_size > 1:
-                    D.allreduce_sum_(self.grad_all, self.pg)
-                st.graphs[1].replay()
+                if len(st.graphs) == 2:
+                    if self.world_size > 1:
+                        D.allreduce_sum_(self.grad_all, self.pg)
+                    st.graphs[1].replay()
                 return st.losses[:7].to(torch.float32)
-        self._compute(st)
-        if self.world_size > 1:
-            D.allreduce_sum_(self.grad_all, self.pg)     # RCCL over xGMI (sum; the Adam kernel scales by 1/world)
-        H.run(st.update, H.current_stream())
+        if self.two_streams:
+            self._step_fused(st)
+        else:
+            self._compute(st)
+            if self.world_size > 1:
+                D.allreduce_sum_(self.grad_all, self.pg)     # RCCL over xGMI (sum; the Adam kernel scales by 1/world)
+            H.run(st.update, H.current_stream())
         st.warm = True
         return st.losses[:7].to(torch.float32)
 

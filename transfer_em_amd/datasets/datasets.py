@@ -67,46 +67,88 @@ def augment(tensor, rng):
 
 
 class Dataset:
-    """Re-iterable batch source: `for batch in dataset`, `next(iter(dataset))`."""
+    """Re-iterable batch source over a fixed sample list: `for batch in dataset`, `next(iter(dataset))`.
 
-    def __init__(self, samples, batch_size, enable_augmentation=False, randomize=False, seed=0, device=None):
+    rank / world_size: data-parallel replicas take interleaved batches (batch b goes to rank b % world_size;
+    the tail that does not fill every rank is dropped so that all ranks run the same number of steps).
+    Every rank draws the same shuffle order (same seed), the augmentation stream is per rank."""
+
+    def __init__(self, samples, batch_size, enable_augmentation=False, randomize=False, seed=0, device=None,
+                 rank=0, world_size=1):
         self.samples, self.batch_size = samples, batch_size
         self.enable_augmentation, self.randomize = enable_augmentation, randomize
-        self.rng = np.random.default_rng(seed)
+        self.order_rng = np.random.default_rng(seed)
+        self.rng = np.random.default_rng([seed, rank])
         self.device = device
+        self.rank, self.world_size = int(rank), int(world_size)
 
     def __len__(self):
-        return len(self.samples) // self.batch_size          # drop_remainder=True
+        return (len(self.samples) // self.batch_size) // self.world_size     # drop_remainder=True
+
+    def _emit(self, items):
+        if self.enable_augmentation:
+            items = [augment(t, self.rng) for t in items]
+        batch = np.stack(items).astype(np.float32)
+        if self.device is not None:
+            import torch
+            batch = torch.from_numpy(np.ascontiguousarray(batch)).to(self.device, non_blocking=True)
+        return batch
 
     def __iter__(self):
-        order = self.rng.permutation(len(self.samples)) if self.randomize else np.arange(len(self.samples))
+        order = self.order_rng.permutation(len(self.samples)) if self.randomize else np.arange(len(self.samples))
         for b in range(len(self)):
-            items = [self.samples[i] for i in order[b * self.batch_size:(b + 1) * self.batch_size]]
-            if self.enable_augmentation:
-                items = [augment(t, self.rng) for t in items]
-            batch = np.stack(items).astype(np.float32)
-            if self.device is not None:
-                import torch
-                batch = torch.from_numpy(np.ascontiguousarray(batch)).to(self.device, non_blocking=True)
-            yield batch
+            gb = b * self.world_size + self.rank
+            yield self._emit([self.samples[i] for i in order[gb * self.batch_size:(gb + 1) * self.batch_size]])
+
+
+class GeneratorDataset(Dataset):
+    """Streams `epoch_size` FRESH samples from an (infinite) python generator every epoch -- no caching, as the
+    reference's generator pipeline does (datasets.py:69-119: "No caching is done ... having more samples is
+    favored over augmentation").  One sample is held at a time; pad / scale / custom map / standardize are
+    applied on the fly.  Data-parallel replicas each own their generator (independent random crops), so
+    every rank simply draws epoch_size // world_size samples."""
+
+    def __init__(self, source, prepare, batch_size, epoch_size, enable_augmentation=False, seed=0, device=None,
+                 rank=0, world_size=1, first=()):
+        super().__init__(None, batch_size, enable_augmentation, False, seed, device, rank, world_size)
+        self.source, self.prepare, self.epoch_size = iter(source), prepare, int(epoch_size)
+        self._first = list(first)            # prepared samples already drawn for the mean/std pass: part of epoch 1
+
+    def __len__(self):
+        return (self.epoch_size // self.world_size) // self.batch_size
+
+    def __iter__(self):
+        items = []
+        for _ in range(len(self) * self.batch_size):
+            if self._first:
+                items.append(self._first.pop(0))
+            else:
+                try:
+                    items.append(self.prepare(next(self.source)))
+                except StopIteration:
+                    return
+            if len(items) == self.batch_size:
+                yield self._emit(items)
+                items = []
+
+
+def _prepare_one(t, custom_map, padding):
+    t = np.asarray(t)
+    if padding is not None:
+        t = np.pad(t, padding, mode="reflect")                # tf.pad(x, padding, "REFLECT")
+    t = scale_tensor(t)
+    if custom_map is not None:
+        t = np.asarray(custom_map(t), np.float32)
+    return t
 
 
 def _prepare(tensors, custom_map, padding):
-    out = []
-    for t in tensors:
-        t = np.asarray(t)
-        if padding is not None:
-            t = np.pad(t, padding, mode="reflect")            # tf.pad(x, padding, "REFLECT")
-        t = scale_tensor(t)
-        if custom_map is not None:
-            t = np.asarray(custom_map(t), np.float32)
-        out.append(t)
-    return out
+    return [_prepare_one(t, custom_map, padding) for t in tensors]
 
 
 def create_dataset_from_tensors(tensors, custom_map=None, batch_size=BATCH_SIZE, enable_augmentation=True,
                                 global_adjust=True, meanstd=None, randomize=False, padding=None, seed=0,
-                                device=None):
+                                device=None, rank=0, world_size=1):
     """Takes a list of numpy arrays (2D or 3D uint8) and creates a dataset (datasets.py:14-67).
 
     Returns (dataset, meanstd); every element is (batch, ..., 1) float32."""
@@ -115,18 +157,36 @@ def create_dataset_from_tensors(tensors, custom_map=None, batch_size=BATCH_SIZE,
         if meanstd is None:
             meanstd = get_meanstd(samples)
         samples = [standardize_population(t, meanstd) for t in samples]
-    return Dataset(samples, batch_size, enable_augmentation, randomize, seed, device), meanstd
+    return Dataset(samples, batch_size, enable_augmentation, randomize, seed, device, rank, world_size), meanstd
+
+
+MEANSTD_SAMPLES = 64   # samples of the stream used for the population statistics when `meanstd` is not given
 
 
 def create_dataset_from_generator(dataset, shape=None, custom_map=None, batch_size=BATCH_SIZE, epoch_size=EPOCH_SIZE,
                                   global_adjust=True, meanstd=None, padding=None, enable_augmentation=False, seed=0,
-                                  device=None):
-    """Takes an (infinite) python generator of 2D/3D uint8 arrays; `epoch_size` samples are drawn
-    (datasets.py:69-119; `shape` is deprecated and ignored there too)."""
-    raw = []
-    for t in dataset:
-        raw.append(t)
-        if len(raw) >= epoch_size:
-            break
-    return create_dataset_from_tensors(raw, custom_map, batch_size, enable_augmentation, global_adjust, meanstd,
-                                       False, padding, seed, device)
+                                  device=None, rank=0, world_size=1):
+    """Takes an (infinite) python generator of 2D/3D uint8 arrays; every epoch draws `epoch_size` fresh samples
+    (datasets.py:69-119; `shape` is deprecated and ignored there too).
+
+    meanstd=None with global_adjust: the reference walks one whole `take(epoch_size)` pass of the stream
+    eagerly (datasets.py:108-111) and then re-draws for training; here the statistics come from one BOUNDED
+    pass -- the first min(epoch_size, MEANSTD_SAMPLES) samples, which are then used as the head of epoch 1
+    instead of being thrown away (mean of per-sample means / variances converges with few 10^6-voxel volumes)."""
+    source = iter(dataset)
+    first = []
+    if global_adjust and meanstd is None:
+        for t in source:
+            first.append(_prepare_one(t, custom_map, padding))
+            if len(first) >= min(int(epoch_size), MEANSTD_SAMPLES):
+                break
+        meanstd = get_meanstd(first)
+    if global_adjust:
+        ms = meanstd
+        prepare = lambda t: standardize_population(_prepare_one(t, custom_map, padding), ms)
+        first = [standardize_population(t, ms) for t in first]
+    else:
+        prepare = lambda t: _prepare_one(t, custom_map, padding)
+    ds = GeneratorDataset(source, prepare, batch_size, epoch_size, enable_augmentation, seed, device, rank, world_size,
+                          first=first)
+    return ds, meanstd

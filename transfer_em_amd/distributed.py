@@ -22,15 +22,6 @@ def allreduce_sum_(flat, group=None):
     return flat
 
 
-def mean_gradient_(flat, group=None):
-    """Average the flat gradient vector over replicas: all-reduce(sum) then scale (the HIP path
-    folds the scale into tem_adam_keras's grad_scale instead)."""
-    allreduce_sum_(flat, group)
-    if is_distributed():
-        flat /= dist.get_world_size(group)
-    return flat
-
-
 def shard(items, rank, world_size):
     """Round-robin shard of independent work items (tiles, volumes) -- no collective needed."""
     return list(items)[rank::world_size]
