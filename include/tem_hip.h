@@ -231,6 +231,19 @@ int tem_u8_to_f32_std(const uint8_t *in, float *out, int64_t n, float mean, floa
 int tem_f32_unstd_to_u8(const tem_view *y, uint8_t *out, int64_t oD, int64_t oH, int64_t oW,
                         float mean, float std, tem_stream_t stream);
 
+/* Tiled inference, input side (utils.py:77-89 with the cloud fetch replaced by a resident uint8 volume
+ * vol[Z][Y][X]): tile t of out[ntile][edge][edge][edge] = the window of `vol` at origin
+ * (z,y,x) = origins_dev[3t..3t+2] -- voxels outside the volume read as 0 -- converted as tem_u8_to_f32_std. */
+int tem_u8_tiles_to_f32_std(const uint8_t *vol, int32_t Z, int32_t Y, int32_t X, const int32_t *origins_dev,
+                            int32_t ntile, int32_t edge, float *out, float mean, float std, tem_stream_t stream);
+
+/* Tiled inference, output side (utils.py:107-126): the interior of tile t of y[ntile][yedge]^3 (`tpad` voxels
+ * stripped per face, utils.py:113-116) is converted as tem_f32_unstd_to_u8 and written into the uint8 volume
+ * out[OZ][OY][OX] at (z,y,x) = index_dev[3t..3t+2].  The caller guarantees the blocks lie inside `out`. */
+int tem_f32_tiles_unstd_to_u8(const float *y, int32_t ntile, int32_t yedge, int32_t tpad, const int32_t *index_dev,
+                              uint8_t *out, int32_t OZ, int32_t OY, int32_t OX, float mean, float std,
+                              tem_stream_t stream);
+
 /* dst[i] = value */
 int tem_fill_f32(float *dst, int64_t n, float value, tem_stream_t stream);
 
@@ -259,6 +272,19 @@ int tem_flip_transpose(const float *theta, float *theta_t, const tem_wlayer *lay
 /* g(view) = saved(view) > 0 ? g : slope * g, in place: LeakyReLU gradient gated on the saved output where no
  * convolution epilogue can carry it (gradient entering the frozen prior network, discriminator.py:62-66). */
 int tem_leaky_gate_view(const tem_view *g, const tem_view *saved, float slope, tem_stream_t stream);
+
+/* InstanceNormalization (models/utils.py:10-38; defined there, every call site commented out at
+ * models/utils.py:75-76,81-82,124-125,131): per sample and channel, over the spatial axes,
+ *   mean, variance = tf.nn.moments(x);  y = scale[c] * (x - mean) * rsqrt(variance + eps) + offset[c].
+ * mean / rstd ([N*C] each) are written for the backward pass. */
+int tem_instance_norm(const tem_view *x, const float *scale, const float *offset, float eps,
+                      const tem_view *y, float *mean, float *rstd, tem_stream_t stream);
+
+/* Gradient of tem_instance_norm: dx (may alias dy), dscale[C], doffset[C] (either may be NULL).
+ * workspace: 2*N*C doubles. */
+int tem_instance_norm_bwd(const tem_view *x, const tem_view *dy, const float *scale, const float *mean,
+                          const float *rstd, const tem_view *dx, float *dscale, float *doffset,
+                          double *workspace, tem_stream_t stream);
 
 /* Library identification: returns TEM_ABI_VERSION; *arch (if non-NULL) receives a
  * static string naming the compiled offload target ("gfx950"). */

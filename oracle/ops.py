@@ -232,6 +232,30 @@ def focal_prob_match(a, b, gamma=2.0):
     return per.sum() / n, dper_dt * dt_db / n
 
 
+# --------------------------------------------------------------------------- InstanceNormalization
+def instance_norm(x, scale, offset, eps=1e-5):
+    """models/utils.py:30-38: mean, variance = tf.nn.moments(x, axes=spatial, keepdims=True);
+    inv = rsqrt(variance + eps); scale * (x - mean) * inv + offset.  Returns (y, mean, rstd) in float64."""
+    x = np.asarray(x, np.float64)
+    mean = x.mean(axis=(1, 2, 3), keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=(1, 2, 3), keepdims=True)          # population variance
+    rstd = 1.0 / np.sqrt(var + eps)
+    return np.asarray(scale, np.float64) * ((x - mean) * rstd) + np.asarray(offset, np.float64), mean, rstd
+
+
+def instance_norm_bwd(x, dy, scale, eps=1e-5):
+    """Adjoint of instance_norm: (dx, dscale, doffset), float64."""
+    x, dy = np.asarray(x, np.float64), np.asarray(dy, np.float64)
+    _, mean, rstd = instance_norm(x, 1.0, 0.0, eps)
+    xh = (x - mean) * rstd
+    ax = (1, 2, 3)
+    dscale = (dy * xh).sum(axis=(0,) + ax)
+    doffset = dy.sum(axis=(0,) + ax)
+    g = dy * np.asarray(scale, np.float64)
+    dx = rstd * (g - g.mean(axis=ax, keepdims=True) - xh * (g * xh).mean(axis=ax, keepdims=True))
+    return dx, dscale, doffset
+
+
 # --------------------------------------------------------------------------- optimizer
 def adam_keras(theta, g, m, v, t, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-7):
     """tf.keras.optimizers.Adam(2e-4, beta_1=0.5) dense update (cgan.py:69-73,218-228).

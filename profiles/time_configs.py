@@ -1,6 +1,6 @@
 """Timing of the two non-headline single-GPU configurations of BASELINE.json (not the bench metric):
 config 3's per-GPU workload (3-D 132^3, batch 2, one train step) and config 4 (260^3 tiled inference,
-generator only, utils.predict_cube incl. host tiling + uint8 boundaries).  Prints one JSON line."""
+generator only, utils.predict_cube: one upload, device-side tile gather / batched forward / uint8 stitch).  Prints one JSON line."""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,10 +19,7 @@ for B in (1, 2):
     out[f"train_volumes_per_s_batch{B}"] = round(B / dt, 1)
 vol = np.random.default_rng(0).integers(0, 256, (260, 260, 260), dtype=np.uint8)
 ms = (127.5, 40.0)
-class G:   # the object predict_cube drives: generator + geometry
-    def __init__(self, em): self.em, self.device, self.outdimsize, self.buffer = em, em.device, em.outdimsize, em.buffer
-    def predict(self, t): return self.em.predict(t)
-g = G(m)
+g = m       # predict_cube drives the model object itself (generator_g, device, outdimsize, buffer)
 utils.predict_cube(vol, (0, 0, 0), (260, 260, 260), g, ms, ms)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 res = utils.predict_cube(vol, (0, 0, 0), (260, 260, 260), g, ms, ms)

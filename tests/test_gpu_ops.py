@@ -316,3 +316,25 @@ def test_uint8_boundaries(H, oracle_lib):
     outu = torch.zeros((5, 6, 7), dtype=torch.uint8, device="cuda")
     H.f32_unstd_to_u8(dev(y), outu, 0.05, 0.6)
     assert np.array_equal(outu.cpu().numpy(), refu)             # byte output: bit-exact
+
+
+def test_instance_normalization(H, oracle_lib):
+    """models/utils.py:10-38 on its HIP kernels (forward, dx, dscale, doffset) vs the oracle, 3-D and 2-D."""
+    from transfer_em_amd.models.utils import InstanceNormalization
+    rng = np.random.default_rng(11)
+    for is3d, shape in ((True, (2, 9, 10, 11, 8)), (False, (3, 17, 19, 16))):
+        x = (rnd(rng, *shape) * 2 + 0.7).astype(np.float32)
+        dy = rnd(rng, *shape)
+        layer = InstanceNormalization(is3d)
+        layer.build(shape[-1], "cuda", seed=5)
+        layer.offset += torch.linspace(-0.5, 0.5, shape[-1], device="cuda")
+        sc, off = layer.scale.cpu().numpy(), layer.offset.cpu().numpy()
+        assert abs(sc.mean() - 1.0) < 0.05 and sc.std() > 0                 # N(1, 0.02)
+        x5 = x if is3d else x[:, None]
+        y_ref, _, _ = oracle_lib.instance_norm(x5, sc, off)
+        y = layer(torch.from_numpy(x))
+        assert tuple(y.shape) == shape and rel_err(y.cpu().numpy().reshape(x5.shape), y_ref) < 2e-6
+        dx_ref, ds_ref, do_ref = oracle_lib.instance_norm_bwd(x5, dy if is3d else dy[:, None], sc)
+        dx, ds, do = layer.backward(torch.from_numpy(dy))
+        assert rel_err(dx.cpu().numpy().reshape(x5.shape), dx_ref) < 1e-5
+        assert rel_err(ds.cpu().numpy(), ds_ref) < 1e-5 and rel_err(do.cpu().numpy(), do_ref) < 1e-5

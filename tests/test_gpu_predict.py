@@ -52,6 +52,52 @@ def test_predict_cube_matches_tilewise_oracle(oracle_lib, tmp_path):
     assert got.std() > 20                                                    # not a degenerate image
 
 
+def test_predict_cube_260_config4(tmp_path):
+    """BASELINE config 4 at full size: a 260^3 request = 27 tiles of 132^3 (out 96, halo 18).  Size-independent
+    properties: (1) the batched device-side pipeline (27 tiles per launch sequence) is bit-identical to running the
+    tiles one at a time; (2) away from the tile seams the stitched volume equals what the 260-edge generator
+    computes on the same data in one piece (translation invariance of the VALID network; Conv3DTranspose('same')
+    zero-pads each tile, which is what makes the reference's tiling visible near tile faces)."""
+    from oracle import graph
+    from transfer_em_amd.cgan import EM2EM
+    from transfer_em_amd.models.generator import unet_generator
+    from transfer_em_amd.utils import predict_cube, tile_plan
+    rng = np.random.default_rng(3)
+    V = rng.integers(0, 256, (296, 296, 296), dtype=np.uint8)               # request + 18 voxels of halo per face
+    model = EM2EM(132, "c4", checkpoint_root=str(tmp_path))
+    P = scaled_params(graph.generator_param_shapes(True), 4)
+    P["f2"] = P["f2"] * 20
+    model.generator_g.params.load_dict(P)
+    ms_x, ms_y = (0.02, 0.58), (-0.1, 0.4)
+    start, size = (18, 18, 18), (260, 260, 260)
+    assert len(tile_plan(start, size, model.outdimsize, model.buffer)[3]) == 27
+    got = predict_cube(V, start, size, model, ms_x, ms_y)
+    one = predict_cube(V, start, size, model, ms_x, ms_y, tile_batch=1)
+    assert got.shape == (260, 260, 260) and got.dtype == np.uint8 and np.array_equal(got, one)
+    assert got.std() > 20
+    big, out_big = unet_generator(260)
+    assert out_big == 224
+    big.params.load_dict(P)
+    x = torch.empty((1, 260, 260, 260, 1), dtype=torch.float32, device="cuda")
+    from transfer_em_amd import hip_ops as H
+    H.u8_to_f32_std(torch.from_numpy(np.ascontiguousarray(V[:260, :260, :260])).cuda(), x.view(-1), *ms_x)
+    yb = big(x)                                                              # (1, 224^3, 1): absolute voxels 18..241
+    ub = torch.zeros((224, 224, 224), dtype=torch.uint8, device="cuda")
+    H.f32_unstd_to_u8(yb, ub, *ms_y)
+    ub = ub.cpu().numpy()
+    m = 12                                                                   # seam margin (see test_generator_260_translation_property)
+    checked = 0
+    for z0 in (0, 96):
+        for y0 in (0, 96):
+            for x0 in (0, 96):
+                sl = (slice(z0 + m, z0 + 96 - m), slice(y0 + m, y0 + 96 - m), slice(x0 + m, x0 + 96 - m))
+                d = got[sl].astype(np.int16) - ub[sl].astype(np.int16)
+                d = np.minimum(np.abs(d), 256 - np.abs(d))
+                assert (d > 1).sum() == 0 and (d != 0).mean() < 0.02, (z0, y0, x0)
+                checked += d.size
+    assert checked == 8 * 72 ** 3
+
+
 def test_simple_training_notebook_flow(tmp_path, capsys):
     """examples/simple_training.ipynb:52-77 end to end on the HIP path: uint8 images -> reflect-padded,
     standardised datasets -> EM2EM(132, 2-D).train(...) with a checkpoint per epoch -> predict -> restore."""

@@ -177,6 +177,41 @@ def test_step_132_schedule_invariance(tmp_path):
         assert np.array_equal(runs[0][1], other[1])
 
 
+def test_step_132_batch2_schedule_invariance(tmp_path):
+    """BASELINE config 3's per-GPU workload (132^3, batch 2): the fused three-stream schedule (gradients, exchange
+    point, Adam on the streams) and the single-stream order give bit-identical losses, parameters and moments."""
+    from transfer_em_amd.cgan import EM2EM
+    shape = (2, 132, 132, 132, 1)
+    rx, ry = torch.from_numpy(_inputs(shape, 31)), torch.from_numpy(_inputs(shape, 32))
+    runs = []
+    for tag, streams in (("a", True), ("b", False)):
+        model = EM2EM(132, f"b2inv{tag}", checkpoint_root=str(tmp_path), two_streams=streams)
+        losses = [model.train_step(rx, ry).cpu().numpy() for _ in range(2)]
+        assert np.isfinite(losses).all()
+        runs.append((np.stack(losses), torch.cat([torch.cat([net.params.theta, net.params.m, net.params.v])
+                                                   for net in model._nets]).cpu().numpy()))
+        del model
+        torch.cuda.empty_cache()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+
+
+def test_checkpoint_restore_by_prefix(tmp_path):
+    """The reference passes tf.train.Checkpoint prefixes ('.../ckpt-N', cgan.py:98-100; utils.save_model's
+    ckpt_dir): accepted next to the literal file name; a wrong path names both candidates."""
+    from transfer_em_amd.cgan import EM2EM
+    m = EM2EM(74, "pre", is3d=False, checkpoint_root=str(tmp_path))
+    x = torch.from_numpy(_inputs((1, 1, 74, 74, 1), 1))
+    m.train_step(x, x)
+    path = m.make_checkpoint(1)
+    assert path.endswith("ckpt-1.pt")
+    m2 = EM2EM(74, "other", is3d=False, ckpt_restore=path[:-3], checkpoint_root=str(tmp_path))
+    assert torch.equal(m2.generator_f.params.theta, m.generator_f.params.theta)
+    with pytest.raises(FileNotFoundError, match="neither"):
+        EM2EM(74, "other2", is3d=False, ckpt_restore=path[:-3] + "7", checkpoint_root=str(tmp_path))
+    with pytest.raises(ValueError, match="train_step: real_x has shape"):          # no silent broadcast into the plan
+        m.train_step(torch.zeros(1, 1, 1, 74, 1), x)
+
+
 def test_generator_260_translation_property():
     """Size-independent property at the largest valid edge (260, BASELINE config 4's tile family): the
     network commutes with translations by multiples of 4 (two stride-2 levels) away from the border,

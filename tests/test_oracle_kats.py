@@ -159,3 +159,24 @@ def test_oracle_reproduces_golden(oracle_lib, tag, is3d, batch, scaled):
         norms = np.array([np.sqrt((np.asarray(v, np.float64) ** 2).sum()) for v in grads["g"].values()])
         assert np.allclose(norms, gold[f"gradnorm_g_{step}"], rtol=1e-6)
     assert np.array_equal(st["g"]["c0"], gold["theta_g_c0_after2"])
+
+
+def test_instance_norm_kat():
+    """models/utils.py:30-38 at hand-computable points: a channel holding {0, 2} in equal numbers has mean 1 and
+    population variance 1 -> normalised values -+1/sqrt(1+eps); the adjoint is orthogonal to constants and to xhat."""
+    from oracle import ops
+    x = np.zeros((1, 2, 2, 2, 1), np.float32)
+    x[0, 1] = 2.0
+    y, mean, rstd = ops.instance_norm(x, [3.0], [0.5], eps=1e-5)
+    assert np.isclose(mean.ravel()[0], 1.0) and np.isclose(rstd.ravel()[0], 1 / np.sqrt(1 + 1e-5))
+    assert np.allclose(y[0, 0], 0.5 - 3 / np.sqrt(1 + 1e-5)) and np.allclose(y[0, 1], 0.5 + 3 / np.sqrt(1 + 1e-5))
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 3, 4, 5, 2))
+    dy = rng.standard_normal(x.shape)
+    dx, ds, do = ops.instance_norm_bwd(x, dy, [1.5, 0.5])
+    assert np.allclose(dx.sum(axis=(1, 2, 3)), 0, atol=1e-12)
+    num = np.zeros_like(x)                                   # finite differences of sum(dy * y)
+    f = lambda xx: (ops.instance_norm(xx, [1.5, 0.5], [0.0, 0.0])[0] * dy).sum()
+    for idx in [(0, 0, 0, 0, 0), (1, 2, 3, 4, 1), (0, 1, 2, 3, 1)]:
+        e = np.zeros_like(x); e[idx] = 1e-6
+        assert np.isclose((f(x + e) - f(x - e)) / 2e-6, dx[idx], rtol=1e-5, atol=1e-8)

@@ -82,11 +82,18 @@ _SIGS = {
     "tem_step_tick": [C.c_void_p, C.c_void_p],
     "tem_u8_to_f32_std": [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p],
     "tem_f32_unstd_to_u8": [_VP, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p],
+    "tem_u8_tiles_to_f32_std": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                C.c_float, C.c_float, C.c_void_p],
+    "tem_f32_tiles_unstd_to_u8": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_float, C.c_float, C.c_void_p],
     "tem_fill_f32": [C.c_void_p, C.c_int64, C.c_float, C.c_void_p],
     "tem_copy_view": [_VP, _VP, C.c_void_p],
     "tem_add_view": [_VP, _VP, C.c_void_p],
     "tem_leaky_gate_view": [_VP, _VP, C.c_float, C.c_void_p],
     "tem_flip_transpose": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p],
+    "tem_instance_norm": [_VP, C.c_void_p, C.c_void_p, C.c_float, _VP, C.c_void_p, C.c_void_p, C.c_void_p],
+    "tem_instance_norm_bwd": [_VP, _VP, C.c_void_p, C.c_void_p, C.c_void_p, _VP, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p],
     "tem_abi_version": [C.POINTER(C.c_char_p)],
 }
 EXPORTS = tuple(_SIGS)

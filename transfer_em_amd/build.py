@@ -1,32 +1,60 @@
-"""Build recipe of libtem_hip.so: hipcc, gfx950 only, in-tree output (transfer_em_amd/lib/)."""
+"""Build recipe of libtem_hip.so: hipcc, gfx950 only, in-tree output (transfer_em_amd/lib/).
+
+Every csrc/*.hip is compiled to its own object (in parallel, only when it or a header changed), then linked."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libtem_hip.so")
-SOURCES = ["conv_direct.hip", "conv_bww.hip", "bww_lds.hip", "conv_lds.hip", "elementwise.hip", "dispatch.hip"]
+OBJ = os.path.join(HERE, "lib", "obj")
+SOURCES = ["conv_direct.hip", "conv_bww.hip", "bww_lds.hip", "conv_lds.hip", "elementwise.hip", "dispatch.hip",
+           "stencil_c1.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-pass-failed"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-pass-failed"]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+           [os.path.join(HERE, "..", "include", "tem_hip.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def needs_build():
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "tem_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    return _stale(OUT, srcs + _headers())
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
+        if not os.path.exists(src):
+            continue
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, s[:-4] + ".o") for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
     return OUT
 
 

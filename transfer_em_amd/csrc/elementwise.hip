@@ -152,6 +152,128 @@ __global__ __launch_bounds__(256) void leaky_gate_view_k(V5 g, V5 sv, float slop
   }
 }
 
+// ---------------------------------------------------------------- InstanceNormalization (models/utils.py:10-38)
+// One workgroup per (n, c): two passes over the channel's voxels (mean, then the mean squared deviation, as
+// tf.nn.moments does), double accumulation, fixed summation order.  Channels-last makes a channel a stride-C
+// gather, but all C workgroups of a sample walk the same cache lines at the same time, so HBM sees one pass.
+__device__ __forceinline__ double block_sum_1024(double s, double *part) {
+  s = wave_sum(s);
+  __syncthreads();                                        // part[] may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+  return t;
+}
+
+__device__ __forceinline__ int64_t vox_off(const V5 &v, int64_t i) {   // i over (D,H,W)
+  int x = (int)(i % v.W); int64_t r = i / v.W;
+  int y = (int)(r % v.H); int z = (int)(r / v.H);
+  return z * v.sD + y * v.sH + x * v.sW;
+}
+
+__global__ __launch_bounds__(1024) void inorm_stats_k(V5 x, float eps, float *mean_out, float *rstd_out) {
+  __shared__ double part[16];
+  const int n = blockIdx.x / x.C, c = blockIdx.x % x.C;
+  const int64_t vox = (int64_t)x.D * x.H * x.W;
+  const float *xp = x.ptr + n * x.sN + c;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < vox; i += blockDim.x) s += (double)xp[vox_off(x, i)];
+  const float mean = (float)(block_sum_1024(s, part) / (double)vox);
+  s = 0.0;
+  for (int64_t i = threadIdx.x; i < vox; i += blockDim.x) {
+    const float d = xp[vox_off(x, i)] - mean;
+    s += (double)(d * d);
+  }
+  const float var = (float)(block_sum_1024(s, part) / (double)vox);
+  if (threadIdx.x == 0) { mean_out[blockIdx.x] = mean; rstd_out[blockIdx.x] = rsqrtf(var + eps); }
+}
+
+// y = scale[c] * ((x - mean[n,c]) * rstd[n,c]) + offset[c]
+__global__ __launch_bounds__(256) void inorm_apply_k(V5 x, V5 y, const float *scale, const float *offset, const float *mean,
+                                                     const float *rstd, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int c, c2;
+    const int64_t xo = voff(x, i, c), yo = voff(y, i, c2);
+    const int n = (int)(i / ((int64_t)x.D * x.H * x.W * x.C));
+    const float nrm = (x.ptr[xo] - mean[n * x.C + c]) * rstd[n * x.C + c];
+    y.ptr[yo] = scale[c] * nrm + offset[c];
+  }
+}
+
+// per (n, c): s1 = sum dy, s2 = sum dy * xhat  (double), written to sums[(n*C + c)*2 + {0,1}]
+__global__ __launch_bounds__(1024) void inorm_bwd_sums_k(V5 x, V5 dy, const float *mean, const float *rstd, double *sums) {
+  __shared__ double part[16];
+  const int n = blockIdx.x / x.C, c = blockIdx.x % x.C;
+  const int64_t vox = (int64_t)x.D * x.H * x.W;
+  const float *xp = x.ptr + n * x.sN + c, *gp = dy.ptr + n * dy.sN + c;
+  const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t i = threadIdx.x; i < vox; i += blockDim.x) {
+    const float g = gp[vox_off(dy, i)], xh = (xp[vox_off(x, i)] - mu) * rs;
+    s1 += (double)g; s2 += (double)(g * xh);
+  }
+  s1 = block_sum_1024(s1, part);
+  s2 = block_sum_1024(s2, part);
+  if (threadIdx.x == 0) { sums[blockIdx.x * 2] = s1; sums[blockIdx.x * 2 + 1] = s2; }
+}
+
+// dx = scale*rstd * (dy - mean(dy) - xhat * mean(dy*xhat));  block 0 also folds the sums over n into dscale / doffset
+__global__ __launch_bounds__(256) void inorm_bwd_apply_k(V5 x, V5 dy, V5 dx, const float *scale, const float *mean,
+                                                         const float *rstd, const double *sums, float *dscale,
+                                                         float *doffset, int64_t total) {
+  const double inv = 1.0 / (double)((int64_t)x.D * x.H * x.W);
+  if (blockIdx.x == 0 && (int)threadIdx.x < x.C) {
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n < x.N; ++n) { a += sums[(n * x.C + threadIdx.x) * 2]; b += sums[(n * x.C + threadIdx.x) * 2 + 1]; }
+    if (doffset) doffset[threadIdx.x] = (float)a;
+    if (dscale) dscale[threadIdx.x] = (float)b;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int c, c2, c3;
+    const int64_t xo = voff(x, i, c), go = voff(dy, i, c2), doo = voff(dx, i, c3);
+    const int nc = (int)(i / ((int64_t)x.D * x.H * x.W * x.C)) * x.C + c;
+    const float xh = (x.ptr[xo] - mean[nc]) * rstd[nc];
+    const float m1 = (float)(sums[nc * 2] * inv), m2 = (float)(sums[nc * 2 + 1] * inv);
+    dx.ptr[doo] = scale[c] * rstd[nc] * (dy.ptr[go] - m1 - xh * m2);
+  }
+}
+
+// ---------------------------------------------------------------- tiled inference boundaries (utils.py:77-126)
+// gather: tile t = the edge^3 window of the uint8 volume at origins[t] (zeros outside), scaled + standardized
+__global__ __launch_bounds__(256) void u8_tiles_to_f32_std_k(const uint8_t *vol, int Z, int Y, int X, const int32_t *origins,
+                                                             int edge, float *out, float mean, float std, int64_t per_tile) {
+  const int t = blockIdx.y;
+  const int oz = origins[3 * t], oy = origins[3 * t + 1], ox = origins[3 * t + 2];
+  float *o = out + (int64_t)t * per_tile;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_tile; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % edge); const int64_t r = i / edge;
+    const int y = (int)(r % edge), z = (int)(r / edge);
+    const int gz = oz + z, gy = oy + y, gx = ox + x;
+    const bool in = (unsigned)gz < (unsigned)Z && (unsigned)gy < (unsigned)Y && (unsigned)gx < (unsigned)X;
+    float v = in ? (float)vol[((int64_t)gz * Y + gy) * X + gx] : 0.f;
+    v = __fsub_rn(__fdiv_rn(v, 127.5f), 1.f);          // datasets.py:200
+    o[i] = __fdiv_rn(__fsub_rn(v, mean), std);         // datasets.py:161-162
+  }
+}
+
+// scatter: the interior (tpad stripped, utils.py:113-116) of tile t of y -> uint8 block of the output volume at index[t]
+__global__ __launch_bounds__(256) void f32_tiles_unstd_to_u8_k(const float *y, int yedge, int tpad, const int32_t *index,
+                                                               uint8_t *out, int OY, int OX, float mean, float std) {
+  const int t = blockIdx.y, od = yedge - 2 * tpad;
+  const int iz = index[3 * t], iy = index[3 * t + 1], ix = index[3 * t + 2];
+  const float *src = y + (int64_t)t * yedge * yedge * yedge;
+  const int64_t per_tile = (int64_t)od * od * od;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_tile; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % od); const int64_t r = i / od;
+    const int yy = (int)(r % od), z = (int)(r / od);
+    float v = src[((int64_t)(z + tpad) * yedge + (yy + tpad)) * yedge + (x + tpad)];
+    v = __fmul_rn(__fadd_rn(__fadd_rn(__fmul_rn(v, std), mean), 1.f), 127.5f);   // utils.py:109, op by op
+    const int q = (int)rintf(v);                                                  // np.around: half to even
+    out[((int64_t)(iz + z) * OY + (iy + yy)) * OX + (ix + x)] = (uint8_t)(q & 0xFF);   // astype(uint8) wraps
+  }
+}
+
 inline unsigned grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -188,6 +310,71 @@ extern "C" int tem_focal_match(const tem_view *a, const tem_view *b, float gamma
   unsigned g = grid_for(total); if (g > 1024) g = 1024;
   hipLaunchKernelGGL(focal_match_k, dim3(g), dim3(256), 0, (hipStream_t)stream, dv(*a), dv(*b), gamma, losses,
                      slot_mask, (double)loss_scale / (double)total, d, grad_scale / (float)total, total);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+extern "C" int tem_instance_norm(const tem_view *x, const float *scale, const float *offset, float eps,
+                                 const tem_view *y, float *mean, float *rstd, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!x || !y || !tem_view_ok(*x) || !tem_view_ok(*y) || !scale || !offset || !mean || !rstd) return TEM_EINVAL;
+  if (!same_extents(*x, *y)) return TEM_ESHAPE;
+  if (x->C > 256) return TEM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(inorm_stats_k, dim3(x->N * x->C), dim3(1024), 0, st, dv(*x), eps, mean, rstd);
+  TEM_CHECK_LAUNCH();
+  const int64_t total = vtotal(*x);
+  hipLaunchKernelGGL(inorm_apply_k, dim3(grid_for(total)), dim3(256), 0, st, dv(*x), dv(*y), scale, offset, mean, rstd, total);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+extern "C" int tem_instance_norm_bwd(const tem_view *x, const tem_view *dy, const float *scale, const float *mean,
+                                     const float *rstd, const tem_view *dx, float *dscale, float *doffset,
+                                     double *workspace, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!x || !dy || !dx || !tem_view_ok(*x) || !tem_view_ok(*dy) || !tem_view_ok(*dx) || !scale || !mean || !rstd ||
+      !workspace)
+    return TEM_EINVAL;
+  if (!same_extents(*x, *dy) || !same_extents(*x, *dx)) return TEM_ESHAPE;
+  if (x->C > 256) return TEM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(inorm_bwd_sums_k, dim3(x->N * x->C), dim3(1024), 0, st, dv(*x), dv(*dy), mean, rstd, workspace);
+  TEM_CHECK_LAUNCH();
+  const int64_t total = vtotal(*x);
+  hipLaunchKernelGGL(inorm_bwd_apply_k, dim3(grid_for(total)), dim3(256), 0, st, dv(*x), dv(*dy), dv(*dx), scale, mean,
+                     rstd, workspace, dscale, doffset, total);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+extern "C" int tem_u8_tiles_to_f32_std(const uint8_t *vol, int32_t Z, int32_t Y, int32_t X, const int32_t *origins_dev,
+                                       int32_t ntile, int32_t edge, float *out, float mean, float std,
+                                       tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!vol || !origins_dev || !out || Z < 1 || Y < 1 || X < 1 || ntile < 0 || edge < 1) return TEM_EINVAL;
+  if (ntile == 0) return TEM_OK;
+  if (ntile > 65535) return TEM_EUNSUPPORTED;
+  const int64_t per_tile = (int64_t)edge * edge * edge;
+  unsigned gx = grid_for(per_tile); if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(u8_tiles_to_f32_std_k, dim3(gx, (unsigned)ntile), dim3(256), 0, (hipStream_t)stream, vol, Z, Y, X,
+                     origins_dev, edge, out, mean, std, per_tile);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+extern "C" int tem_f32_tiles_unstd_to_u8(const float *y, int32_t ntile, int32_t yedge, int32_t tpad,
+                                         const int32_t *index_dev, uint8_t *out, int32_t OZ, int32_t OY, int32_t OX,
+                                         float mean, float std, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!y || !index_dev || !out || ntile < 0 || yedge < 1 || tpad < 0 || 2 * tpad >= yedge || OZ < 1 || OY < 1 || OX < 1)
+    return TEM_EINVAL;
+  if (ntile == 0) return TEM_OK;
+  if (ntile > 65535) return TEM_EUNSUPPORTED;
+  const int od = yedge - 2 * tpad;
+  unsigned gx = grid_for((int64_t)od * od * od); if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(f32_tiles_unstd_to_u8_k, dim3(gx, (unsigned)ntile), dim3(256), 0, (hipStream_t)stream, y, yedge, tpad,
+                     index_dev, out, OY, OX, mean, std);
   TEM_CHECK_LAUNCH();
   return TEM_OK;
 }

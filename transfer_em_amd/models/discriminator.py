@@ -13,6 +13,7 @@ import torch
 from .. import hip_ops as H
 from .params import ParamSet
 from .prior import PriorBackward, PriorForward
+from .utils import ConvSpec, downsample, kernel_shape
 
 DOUBLE_LEAKY = float(torch.tensor(0.3, dtype=torch.float32) * torch.tensor(0.3, dtype=torch.float32))
 
@@ -23,22 +24,22 @@ def discriminator_param_shapes(is3d=True, wf=8, prior_channels=0):
     if prior_channels not in (0, 32):
         # discriminator.py:62-66: Downsample_3 is built for dims = 64 = 32 + the prior's channels
         raise RuntimeError("disc_prior must output 32 channels (Downsample_3 expects 64 input channels)")
-    k3 = (3, 3, 3) if is3d else (1, 3, 3)
-    k4 = (4, 4, 4) if is3d else (1, 4, 4)
-    k1 = (1, 1, 1)
-    s = OrderedDict()
+    conv = lambda k, ci, co, act="leaky_relu(0.3)": ConvSpec("conv", k, 1, "valid", ci, co, act)
+    B = OrderedDict()
     if is3d:
-        s["d1a"] = k3 + (1, 64 // wf)                 # Downsample_1 (discriminator.py:39-40)
-        s["d1b"] = k4 + (64 // wf, 64 // wf)
-        s["hack"] = k3 + (64 // wf, 16)               # discriminator.py:45-47
+        down1, _ = downsample("1", 1, 64 // wf, is3d)              # discriminator.py:39-40
+        B["d1a"], B["d1b"] = down1
+        B["hack"] = conv(3, 64 // wf, 16)                          # discriminator.py:45-47
     else:
-        s["hack"] = k3 + (1, 16)                      # discriminator.py:49-51 (raw input)
-    s["d2a"] = k3 + (128 // wf, 256 // wf)            # Downsample_2
-    s["d2b"] = k4 + (256 // wf, 256 // wf)
-    s["d3a"] = k3 + (32 + prior_channels, 32)         # Downsample_3 (dims=32 hard-coded, :60,72; 64 with a prior, :66)
-    s["d3b"] = k4 + (32, 32)
-    s["p1"] = k1 + (32, 256 // wf)                    # discriminator.py:78-80
-    s["p2"] = k1 + (256 // wf, 1)                     # discriminator.py:97-99 (with bias)
+        B["hack"] = conv(3, 1, 16)                                 # discriminator.py:49-51 (raw input)
+    down2, _ = downsample("2", 128 // wf, 256 // wf, is3d)         # discriminator.py:57-58
+    B["d2a"], B["d2b"] = down2
+    down3, _ = downsample("3", 32 + prior_channels, 32, is3d)      # dims=32 hard-coded (:60,72); 64 with a prior (:66)
+    B["d3a"], B["d3b"] = down3
+    B["p1"] = conv(1, 32, 256 // wf)                               # discriminator.py:78-80
+    B["p2"] = conv(1, 256 // wf, 1, "linear+bias")                 # discriminator.py:97-99 (with bias)
+    s = OrderedDict((name, kernel_shape(spec, is3d) if spec.kernel > 1 else (1, 1, 1, spec.in_ch, spec.out_ch))
+                    for name, spec in B.items())
     s["p2_bias"] = (1,)
     return s
 

@@ -13,6 +13,7 @@ import torch
 
 from .. import hip_ops as H
 from .params import ParamSet
+from .utils import ConvSpec, downsample, kernel_shape, upsample
 
 # technically invalid sizes will still work but off-by-one problems could arise (generator.py:17-20).
 # The mounted reference lists only 74; 132 is what every notebook, utils.save_model and
@@ -50,19 +51,29 @@ def skip_crop(dim_dn, dim_up):
     return c1, c1 + ((dim_dn - dim_up) % 2)
 
 
-def generator_param_shapes(is3d=True, wf=8):
+def generator_blocks(is3d=True, wf=8):
+    """The generator as the reference assembles it (generator.py:53-115): first conv, Downsample_1/2, Upsample_2,
+    the mid conv, Upsample_1 and the two final convs -- blocks from models/utils.downsample / upsample."""
     c1, c2, cm, cf = 64 // wf, 128 // wf, 256 // wf, 128 // wf
-    k3 = (3, 3, 3) if is3d else (1, 3, 3)
-    k4 = (4, 4, 4) if is3d else (1, 4, 4)
+    conv3 = lambda ci, co, act="leaky_relu(0.3)": ConvSpec("conv", 3, 1, "valid", ci, co, act)
+    down1, _ = downsample("1", c1, c1, is3d)                       # generator.py:60
+    down2, _ = downsample("2", c1, c2, is3d)                       # generator.py:67
+    up2 = upsample("2", c2, c2, is3d)                              # generator.py:90
+    up1 = upsample("1", cm, c1, is3d)                              # generator.py:102
     return OrderedDict([
-        ("c0", k3 + (1, c1)),                                        # generator.py:53-56
-        ("d1a", k3 + (c1, c1)), ("d1b", k4 + (c1, c1)),              # Downsample_1
-        ("d2a", k3 + (c1, c2)), ("d2b", k4 + (c2, c2)),              # Downsample_2
-        ("u2a", k3 + (c2, 2 * c2)), ("u2b", k4 + (c2, 2 * c2)),      # Upsample_2 (transposed: ..., CO, CI)
-        ("mid", k3 + (2 * c2, cm)),                                  # generator.py:95-98
-        ("u1a", k3 + (cm, 2 * c1)), ("u1b", k4 + (c1, 2 * c1)),      # Upsample_1
-        ("f1", k3 + (2 * c1, cf)), ("f2", k3 + (cf, 1)),             # generator.py:107-114
+        ("c0", conv3(1, c1)),                                      # generator.py:53-56
+        ("d1a", down1[0]), ("d1b", down1[1]),
+        ("d2a", down2[0]), ("d2b", down2[1]),
+        ("u2a", up2[0]), ("u2b", up2[1]),
+        ("mid", conv3(2 * c2, cm)),                                # generator.py:95-98 (input = [upsampled | skip1])
+        ("u1a", up1[0]), ("u1b", up1[1]),
+        ("f1", conv3(2 * c1, cf)), ("f2", conv3(cf, 1, "linear")),  # generator.py:107-114
     ])
+
+
+def generator_param_shapes(is3d=True, wf=8):
+    """Keras kernel shapes in creation order, from the block descriptions."""
+    return OrderedDict((name, kernel_shape(spec, is3d)) for name, spec in generator_blocks(is3d, wf).items())
 
 
 def dropout_site(call_id, block):
@@ -293,16 +304,22 @@ class UNetGenerator:
     def forward_plan(self, x, **kw):
         return GenForward(self, x, **kw)
 
+    def plan(self, shape):
+        """Cached inference launch plan for inputs of `shape` (N, D, H, W, 1): fill `plan.x`, call `plan.run()`;
+        the result `plan.y` is overwritten by the next run."""
+        key = tuple(int(v) for v in shape)
+        plan = self._plans.get(key)
+        if plan is None:
+            buf = torch.empty(key, dtype=torch.float32, device=self.device)
+            plan = self._plans[key] = GenForward(self, buf)
+        return plan
+
     def __call__(self, x, training=False):
         """Inference forward (Keras __call__ without training=True: dropout off, cgan.py:289-293)."""
         if training:
             raise NotImplementedError("training-mode calls go through EM2EM.train_step")
         x = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
-        key = tuple(x.shape)
-        plan = self._plans.get(key)
-        if plan is None:
-            buf = torch.empty_like(x)
-            plan = self._plans[key] = GenForward(self, buf)
+        plan = self.plan(x.shape)
         plan.x.copy_(x)
         return plan.run().clone()
 

@@ -1,16 +1,24 @@
 """Helper builders (mirror of reference transfer_em/models/utils.py).
 
 The reference's `downsample` / `upsample` return Keras sub-models; here they return the block
-descriptions the generator / discriminator launch plans are made of (kernel shapes in Keras
-layout, geometry, activation), so code that inspects blocks keeps working.  Normalisation is
+descriptions (kernel shape in Keras layout, geometry, activation) that models/generator.py and
+models/discriminator.py build their parameter tables and launch plans from.  Normalisation is
 disabled in the reference (models/utils.py:75-76,81-82,124-125,131 are commented out), so
-`norm_type` / `apply_norm` are accepted and ignored exactly as there.
+`norm_type` / `apply_norm` are accepted and ignored exactly as there; `InstanceNormalization` itself
+(models/utils.py:10-38) is provided as a layer over its own HIP kernels for users who re-enable it.
 """
+import ctypes as C
 from collections import namedtuple
 
 import torch
 
 ConvSpec = namedtuple("ConvSpec", "kind kernel stride padding in_ch out_ch activation")
+
+
+def kernel_shape(spec, is3d):
+    """Keras kernel shape of a block layer: Conv (k.., C_in, C_out); ConvTranspose (k.., C_out, C_in)."""
+    k = (spec.kernel,) * 3 if is3d else (1, spec.kernel, spec.kernel)
+    return k + ((spec.in_ch, spec.out_ch) if spec.kind == "conv" else (spec.out_ch, spec.in_ch))
 
 
 def downsample(id, infilters, outfilters, is3d, filter_size=4, norm_type='instancenorm', apply_norm=True):
@@ -32,19 +40,55 @@ def upsample(id, infilters, outfilters, is3d, filter_size=4, norm_type='instance
 
 class InstanceNormalization:
     """Instance Normalization Layer (https://arxiv.org/abs/1607.08022), models/utils.py:10-38.
-    Defined for API completeness; never instantiated on the hot path (dead code in the reference too)."""
+
+    `scale` ~ N(1, 0.02), `offset` = 0 (build, models/utils.py:18-28); __call__ normalises a float32
+    channels-last CUDA tensor (N, [D,] H, W, C) over its spatial axes with the HIP kernels behind
+    tem_instance_norm; `backward(dy)` returns (dx, dscale, doffset) for the last call.  Dead code on the
+    reference's hot path (every call site is commented out), so it is not part of EM2EM's launch plans."""
 
     def __init__(self, is3d=True, epsilon=1e-5):
         self.epsilon, self.is3d, self.scale, self.offset = epsilon, is3d, None, None
+        self._saved = None
 
-    def build(self, channels, device="cpu"):
-        self.scale = torch.normal(1.0, 0.02, (channels,), device=device)
+    def build(self, channels, device="cuda", seed=None):
+        gen = torch.Generator(device="cpu")
+        if seed is not None:
+            gen.manual_seed(int(seed))
+        self.scale = (1.0 + 0.02 * torch.randn(channels, generator=gen)).to(device)
         self.offset = torch.zeros(channels, device=device)
 
+    def _v5(self, t):
+        from .. import hip_ops as H
+        return H.view(t if t.dim() == 5 else t.unsqueeze(1))
+
     def __call__(self, x):
+        from .. import _lib, hip_ops as H
+        lib = H.require_gpu()
+        x = torch.as_tensor(x, dtype=torch.float32).to(self.scale.device if self.scale is not None else "cuda").contiguous()
         if self.scale is None:
             self.build(x.shape[-1], x.device)
-        axes = (1, 2, 3) if self.is3d else (1, 2)
-        mean = x.mean(dim=axes, keepdim=True)
-        var = x.var(dim=axes, keepdim=True, unbiased=False)
-        return self.scale * ((x - mean) * torch.rsqrt(var + self.epsilon)) + self.offset
+        assert x.dim() == (5 if self.is3d else 4), "expects (N, [D,] H, W, C)"
+        y = torch.empty_like(x)
+        nc = x.shape[0] * x.shape[-1]
+        mean = torch.empty(nc, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        vx, vy = self._v5(x), self._v5(y)
+        _lib.check(lib.tem_instance_norm(C.byref(vx), self.scale.data_ptr(), self.offset.data_ptr(), float(self.epsilon),
+                                         C.byref(vy), mean.data_ptr(), rstd.data_ptr(), H.current_stream()),
+                   "tem_instance_norm")
+        self._saved = (x, mean, rstd)
+        return y
+
+    def backward(self, dy):
+        from .. import _lib, hip_ops as H
+        lib = H.require_gpu()
+        x, mean, rstd = self._saved
+        dy = torch.as_tensor(dy, dtype=torch.float32).to(x.device).contiguous()
+        dx = torch.empty_like(x)
+        dscale, doffset = torch.empty_like(self.scale), torch.empty_like(self.offset)
+        ws = torch.empty(2 * mean.numel(), dtype=torch.float64, device=x.device)
+        vx, vg, vd = self._v5(x), self._v5(dy), self._v5(dx)
+        _lib.check(lib.tem_instance_norm_bwd(C.byref(vx), C.byref(vg), self.scale.data_ptr(), mean.data_ptr(),
+                                             rstd.data_ptr(), C.byref(vd), dscale.data_ptr(), doffset.data_ptr(),
+                                             ws.data_ptr(), H.current_stream()), "tem_instance_norm_bwd")
+        return dx, dscale, doffset

@@ -33,12 +33,23 @@ def tile_plan(start, size, outdimsize, buffer):
     return outdimsize, buffer, tpad, rois, index
 
 
+TILE_BATCH = 27      # tiles per generator launch sequence (27 x 132^3: ~10 GB of activations; 288 GB HBM)
+
+
 def predict_cube(volume, start, size, model, meanstd_x, meanstd_y, fetch_input=False, outdimsize=None, buffer=None,
-                 rank=0, world_size=1):
+                 rank=0, world_size=1, tile_batch=None):
     """Predict the subvolume [start, start+size) (x,y,z order as in the reference) of a uint8
     array `volume` indexed [z, y, x].  Voxels outside the array read as 0 (the reference fetches
-    them from the store).  Returns uint8 (zsize, ysize, xsize) [and the input block]."""
-    volume = np.ascontiguousarray(volume, dtype=np.uint8)
+    them from the store).  Returns uint8 (zsize, ysize, xsize) [and the input block].
+
+    Device-side pipeline (utils.py:77-126 without the per-tile host round trips): the uint8 volume is uploaded
+    once; one gather kernel cuts a batch of haloed tiles straight out of it (uint8 -> float, scaled and
+    standardized, tem_u8_tiles_to_f32_std); the generator runs the batch as ONE launch sequence (batch = tile
+    count: the small inner layers then fill the chip); one scatter kernel un-standardizes, rounds and writes
+    every tile's interior into the uint8 output volume (tem_f32_tiles_unstd_to_u8).  Tile geometry, halo and
+    the "multiple of 6" quirk are the reference's (tile_plan)."""
+    from . import _lib
+    lib = H.require_gpu()
     if outdimsize is None:
         outdimsize = model.outdimsize
     if buffer is None:
@@ -48,34 +59,46 @@ def predict_cube(volume, start, size, model, meanstd_x, meanstd_y, fetch_input=F
     z, y, x = size[2], size[1], size[0]
     rnd = lambda v: v + ((outdimsize - (v % outdimsize)) if (v % outdimsize) != 0 else 0)
     dev = model.device
+    vol_host = np.ascontiguousarray(volume, dtype=np.uint8)
+    vol = torch.from_numpy(vol_host).to(dev, non_blocking=True)          # ONE upload of the whole volume
+    Z, Y, X = vol_host.shape
     out_buffer = torch.zeros((rnd(z), rnd(y), rnd(x)), dtype=torch.uint8, device=dev)
-    tile_u8 = torch.empty((edge, edge, edge), dtype=torch.uint8, device=dev)
-    tile_f = torch.empty((1, edge, edge, edge, 1), dtype=torch.float32, device=dev)
-    Z, Y, X = volume.shape
-    for idx in range(rank, len(rois), world_size):
-        rx, ry, rz = rois[idx]
-        host = np.zeros((edge, edge, edge), np.uint8)
-        z0, y0, x0 = max(rz, 0), max(ry, 0), max(rx, 0)
-        z1, y1, x1 = min(rz + edge, Z), min(ry + edge, Y), min(rx + edge, X)
-        if z1 > z0 and y1 > y0 and x1 > x0:
-            host[z0 - rz:z1 - rz, y0 - ry:y1 - ry, x0 - rx:x1 - rx] = volume[z0:z1, y0:y1, x0:x1]
-        tile_u8.copy_(torch.from_numpy(host))
-        H.u8_to_f32_std(tile_u8, tile_f.view(-1), meanstd_x[0], meanstd_x[1])
-        data_y = model.predict(tile_f)
-        if tpad > 0:
-            data_y = data_y[:, tpad:-tpad, tpad:-tpad, tpad:-tpad, :]
-        ix, iy, iz = index[idx]
-        H.f32_unstd_to_u8(data_y, out_buffer[iz:iz + outdimsize, iy:iy + outdimsize, ix:ix + outdimsize],
-                          meanstd_y[0], meanstd_y[1])
+    OZ, OY, OX = out_buffer.shape
+    mine = list(range(rank, len(rois), world_size))
+    nb = max(1, min(int(tile_batch or TILE_BATCH), len(mine) or 1))
+    gen = getattr(model, "generator_g", None)
+    stream = H.current_stream()
+    for c0 in range(0, len(mine), nb):
+        chunk = mine[c0:c0 + nb]
+        n = len(chunk)
+        org = torch.tensor([[rois[i][2], rois[i][1], rois[i][0]] for i in chunk], dtype=torch.int32).to(dev)   # (z,y,x)
+        idx = torch.tensor([[index[i][2], index[i][1], index[i][0]] for i in chunk], dtype=torch.int32).to(dev)
+        if hasattr(gen, "plan"):
+            plan = gen.plan((n, edge, edge, edge, 1))                      # static launch plan, buffers reused
+            tiles = plan.x
+        else:
+            plan, tiles = None, torch.empty((n, edge, edge, edge, 1), dtype=torch.float32, device=dev)
+        _lib.check(lib.tem_u8_tiles_to_f32_std(vol.data_ptr(), Z, Y, X, org.data_ptr(), n, edge, tiles.data_ptr(),
+                                               float(meanstd_x[0]), float(meanstd_x[1]), stream),
+                   "tem_u8_tiles_to_f32_std")
+        data_y = plan.run() if plan is not None else model.predict(tiles).contiguous()
+        yedge = data_y.shape[1]
+        assert yedge - 2 * tpad == outdimsize, (yedge, tpad, outdimsize)
+        _lib.check(lib.tem_f32_tiles_unstd_to_u8(data_y.data_ptr(), n, yedge, tpad, idx.data_ptr(), out_buffer.data_ptr(),
+                                                 OZ, OY, OX, float(meanstd_y[0]), float(meanstd_y[1]), stream),
+                   "tem_f32_tiles_unstd_to_u8")
     if world_size > 1 and torch.distributed.is_initialized():
         torch.distributed.all_reduce(out_buffer, op=torch.distributed.ReduceOp.MAX)   # disjoint tiles, zeros elsewhere
     out = out_buffer[0:size[2], 0:size[1], 0:size[0]].cpu().numpy()
     if fetch_input:
+        # the reference returns the RAW uint8 block here after a detour (utils.py:122-125: the standardized float
+        # tile is un-standardized, rescaled and truncated into a uint8 buffer -- the original bytes up to float
+        # rounding); the bytes themselves are returned instead
         inp = np.zeros((size[2], size[1], size[0]), np.uint8)
         z0, y0, x0 = max(start[2], 0), max(start[1], 0), max(start[0], 0)
         z1, y1, x1 = min(start[2] + size[2], Z), min(start[1] + size[1], Y), min(start[0] + size[0], X)
         inp[z0 - start[2]:z1 - start[2], y0 - start[1]:y1 - start[1], x0 - start[0]:x1 - start[0]] = \
-            volume[z0:z1, y0:y1, x0:x1]
+            vol_host[z0:z1, y0:y1, x0:x1]
         return inp, out
     return out
 
