@@ -338,3 +338,39 @@ def test_instance_normalization(H, oracle_lib):
         dx, ds, do = layer.backward(torch.from_numpy(dy))
         assert rel_err(dx.cpu().numpy().reshape(x5.shape), dx_ref) < 1e-5
         assert rel_err(ds.cpu().numpy(), ds_ref) < 1e-5 and rel_err(do.cpu().numpy(), do_ref) < 1e-5
+
+
+@pytest.mark.parametrize("CI,CO,flip", [(1, 8, False), (1, 16, True), (16, 1, False), (8, 1, True)])
+def test_c1_stencil_tiles_views_and_pads(H, oracle_lib, CI, CO, flip):
+    """stencil_c1.hip (the HBM-bound one-channel layers): several patches and z-runs with ragged ends, batch 2,
+    a cropped view as input, positive and negative padding, the fused gate -- vs the oracle and vs the direct kernel."""
+    rng = np.random.default_rng(CI * 31 + CO)
+    for n, pad, crop in ((45, 0, 0), (23, 2, 0), (30, -1, 3)):
+        full = rnd(rng, 2, n + 2 * crop, n + 2 * crop + 1, n + 2 * crop + 3, CI)
+        xd = dev(full)
+        xv = xd[:, crop:crop + n, crop:crop + n + 1, crop:crop + n + 3, :] if crop else xd
+        x = full[:, crop:crop + n, crop:crop + n + 1, crop:crop + n + 3, :] if crop else full
+        if flip:        # input-gradient form: Keras kernel of the forward layer (C_out_fwd = CI here), flipped taps
+            w = rnd(rng, 3, 3, 3, CO, CI) * 0.2
+            weff = np.ascontiguousarray(w[::-1, ::-1, ::-1].transpose(0, 1, 2, 4, 3))
+        else:
+            w = rnd(rng, 3, 3, 3, CI, CO) * 0.2
+            weff = w
+        xin = x
+        if pad < 0:
+            xin, p_eff = x[:, -pad:pad, -pad:pad, -pad:pad, :], 0
+        else:
+            p_eff = pad
+        conv = oracle_lib.conv_fwd(xin, weff, 1, p_eff)
+        saved = rnd(rng, *conv.shape)
+        ref = oracle_lib.leaky_relu_grad_from_out(conv, saved)
+        outs = []
+        for direct in (False, True):
+            out = torch.empty(ref.shape, dtype=torch.float32, device="cuda")
+            launch = H.conv_launch("t", xv, dev(w.reshape(-1)), out, 3, 1, pad, gate=dev(saved),
+                                   layout=H.TEM_W_FLIP_CO_CI if flip else H.TEM_W_TAP_CI_CO, direct=direct)
+            H.run([launch])
+            outs.append(out.cpu().numpy())
+            if not direct:
+                assert launch.meta["kernel"].startswith("c1_"), launch.meta["kernel"]
+        assert rel_err(outs[0], ref) < TOL and rel_err(outs[1], ref) < TOL, (n, pad, crop)
