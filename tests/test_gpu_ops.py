@@ -374,3 +374,31 @@ def test_c1_stencil_tiles_views_and_pads(H, oracle_lib, CI, CO, flip):
             if not direct:
                 assert launch.meta["kernel"].startswith("c1_"), launch.meta["kernel"]
         assert rel_err(outs[0], ref) < TOL and rel_err(outs[1], ref) < TOL, (n, pad, crop)
+
+
+@pytest.mark.parametrize("CI,CO", [(16, 8), (32, 16), (8, 8), (16, 16), (32, 32)])
+def test_conv_transpose_mfma_shifted_windows(H, oracle_lib, CI, CO):
+    """convT_mfma.hip: the parity-class GEMM form of the k4 s2 transposed convolution, for every channel pair the
+    step uses, batch 2, with the shifted paddings of region-restricted execution (output = a window of the full
+    result: p' = p + lo_out - 2 lo_in, any sign), odd and even extents, gate + add -- vs the oracle and the direct kernel."""
+    rng = np.random.default_rng(CI * 3 + CO)
+    w = rnd(rng, 4, 4, 4, CO, CI) * 0.1
+    for n, pad, lo, osz in ((9, 1, 0, 18), (7, 1, 3, 9), (6, 0, 2, 11), (5, 0, 0, 12)):
+        x = rnd(rng, 2, n, n, n, CI)
+        full = oracle_lib.convT_fwd(x, w, 2, pad, out_dims=(2 * n + 2 - 2 * pad,) * 3)
+        win = full[:, lo:lo + osz, lo:lo + osz, lo:lo + osz, :]
+        saved = rnd(rng, *win.shape)
+        addw = rnd(rng, 2, osz - 2, osz - 2, osz - 2, CO)
+        ref = win.copy()
+        ref[:, 1:-1, 1:-1, 1:-1, :] += addw
+        ref = oracle_lib.leaky_relu_grad_from_out(ref, saved)
+        outs = []
+        for direct in (False, True):
+            out = torch.empty(ref.shape, dtype=torch.float32, device="cuda")
+            launch = H.conv_launch("t", dev(x), dev(w.reshape(-1)), out, 4, 2, pad + lo, transposed=True, gate=dev(saved),
+                                   add=dev(addw), add_off=1, direct=direct)
+            H.run([launch])
+            outs.append(out.cpu().numpy())
+            if not direct:
+                assert launch.meta["kernel"].startswith("convT_mfma_k"), launch.meta["kernel"]
+        assert rel_err(outs[0], ref) < TOL and rel_err(outs[1], ref) < TOL, (n, pad, lo, osz)
