@@ -244,6 +244,20 @@ int tem_f32_tiles_unstd_to_u8(const float *y, int32_t ntile, int32_t yedge, int3
                               uint8_t *out, int32_t OZ, int32_t OY, int32_t OX, float mean, float std,
                               tem_stream_t stream);
 
+/* Random augmentation of one cached sample (datasets.py:123-155) with host-drawn parameters:
+ *   dst = reverse(transpose(src, perm = (p0,p1,p2)), dims with f_k != 0) * scale + shift
+ * src is a dense single-channel (D,H,W) volume (2-D: D == 1, p0 must be 0); dst has extents
+ * (dim[p0], dim[p1], dim[p2]) and must not alias src. */
+int tem_augment_f32(const float *src, int32_t D, int32_t H, int32_t W, int32_t p0, int32_t p1, int32_t p2,
+                    int32_t f0, int32_t f1, int32_t f2, float scale, float shift, float *dst, tem_stream_t stream);
+
+/* debug.warp_tensor (debug.py:7-63) on the device: dst = box blur of src (3 wide per non-unit axis, zero SAME
+ * padding); hole seeds ~ Bernoulli(rate) per voxel (Philox stream of `seed`, written to `seeds`, one byte per
+ * voxel), dilated by a 4-wide box (SAME: 1 before, 2 after); holes := mean(blurred).  `sum`: one double of
+ * workspace.  dst must not alias src. */
+int tem_warp_f32(const float *src, int32_t D, int32_t H, int32_t W, float rate, uint64_t seed, float *dst,
+                 uint8_t *seeds, double *sum, tem_stream_t stream);
+
 /* dst[i] = value */
 int tem_fill_f32(float *dst, int64_t n, float value, tem_stream_t stream);
 

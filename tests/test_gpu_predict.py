@@ -155,3 +155,32 @@ def test_saved_model_export_and_tiled_predict(tmp_path):
     assert live.shape == (40, 41, 45) and np.array_equal(live, saved)
     with pytest.raises(NotImplementedError):
         utils.predict_ng_cube("gs://bucket/volume", start, size, model, ms_x, ms_y)
+
+
+def test_device_data_pipeline_matches_host():
+    """SURVEY 8(f) row 2 on the device: augmentation (datasets.py:123-155) and the warp (debug.py:7-63) as HIP kernels
+    give the numbers of the host (numpy) pipeline: augmentation bit for bit (same generator draws), the warp for the
+    same hole seeds."""
+    from transfer_em_amd.datasets import datasets as D
+    from transfer_em_amd.debug import warp_tensor, warp_tensor_device
+    rng = np.random.default_rng(2)
+    for shape in ((20, 20, 20), (33, 33)):
+        imgs = [rng.integers(0, 256, shape, dtype=np.uint8) for _ in range(6)]
+        host, ms = D.create_dataset_from_tensors(imgs, batch_size=2, enable_augmentation=True, randomize=True, seed=7)
+        devd, _ = D.create_dataset_from_tensors(imgs, batch_size=2, enable_augmentation=True, randomize=True, seed=7,
+                                                meanstd=ms, device="cuda")
+        for epoch in range(2):
+            for hb, db in zip(host, devd):
+                assert db.is_cuda and np.array_equal(hb, db.cpu().numpy()), (shape, epoch)
+    class Fixed:                                   # feeds the device kernel's seeds to the host reference
+        def __init__(self, seeds): self.seeds = seeds
+        def uniform(self, lo, hi, shape): return np.where(self.seeds, 0.0, 1.0)
+    for shape in ((40, 41, 42, 1), (130, 129, 1)):
+        x = (rng.standard_normal(shape) * 0.5).astype(np.float32)
+        out, seeds = warp_tensor_device(torch.from_numpy(x).cuda(), seed=11, return_seeds=True)
+        seeds = seeds.cpu().numpy().astype(bool)
+        n = seeds.size
+        assert 0 < seeds.sum() < 10 * n * 4.0 / (128 * 128) + 10            # Bernoulli(4/128^2) seeds
+        ref = warp_tensor(x, Fixed(seeds))
+        assert np.abs(out.cpu().numpy() - ref).max() < 1e-6
+        assert (ref == ref.reshape(-1)[np.argmax(seeds.reshape(-1))]).sum() >= 8   # a hole really was punched

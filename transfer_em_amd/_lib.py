@@ -86,6 +86,10 @@ _SIGS = {
                                 C.c_float, C.c_float, C.c_void_p],
     "tem_f32_tiles_unstd_to_u8": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_float, C.c_float, C.c_void_p],
+    "tem_augment_f32": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                        C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
+    "tem_warp_f32": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                     C.c_void_p],
     "tem_fill_f32": [C.c_void_p, C.c_int64, C.c_float, C.c_void_p],
     "tem_copy_view": [_VP, _VP, C.c_void_p],
     "tem_add_view": [_VP, _VP, C.c_void_p],

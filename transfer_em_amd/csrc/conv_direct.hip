@@ -429,6 +429,14 @@ static int conv_direct_impl(const tem_conv_args *a, hipStream_t st, char *name, 
       ROWS_CASE(1, 8, false, 3, 1, 4) ROWS_CASE(8, 1, true, 3, 1, 4)
       ROWS_CASE(16, 1, false, 3, 1, 4) ROWS_CASE(1, 16, true, 3, 1, 4)
     }
+    // TEM_ROWS2 (bit mask, perf triage): row-blocked form for the k4 s2 layers (bit 0), 8->16 / 16->8 k3 (bit 1)
+    static int rows2 = -1;
+    if (rows2 < 0) { const char *v = getenv("TEM_ROWS2"); rows2 = v ? atoi(v) : 0; }
+    if (p.OH >= 16 && a->kw == a->kh && a->kd == a->kh) {
+      if (rows2 & 1) { ROWS_CASE(8, 8, false, 4, 2, 2) ROWS_CASE(8, 16, false, 4, 2, 2) }
+      if (rows2 & 4) { ROWS_CASE(8, 8, false, 4, 2, 4) ROWS_CASE(8, 16, false, 4, 2, 4) }
+      if (rows2 & 2) { ROWS_CASE(8, 16, false, 3, 1, 4) ROWS_CASE(16, 8, false, 3, 1, 4) }
+    }
   }
   if (name) {
     static const int table[][4] = {{1, 0, 8, 0}, {1, 0, 16, 0}, {1, 0, 32, 0}, {8, 0, 8, 0}, {8, 0, 16, 0}, {8, 0, 1, 0},

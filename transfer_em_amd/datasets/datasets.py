@@ -56,14 +56,44 @@ def get_meanstd(dataset):
 def augment(tensor, rng):
     """Random axis permutation, flips and intensity / variance jitter (datasets.py:123-155)."""
     ndims = tensor.ndim - 1
-    perm = list(rng.permutation(ndims)) + [ndims]
-    tensor = np.transpose(tensor, perm)
+    perm, flips, mean_adj, var_adj = _augment_params(ndims, rng)
+    tensor = np.transpose(tensor, perm + [ndims])
     for dim in range(ndims):
-        if rng.uniform(0, 1.0) < .5:
+        if flips[dim]:
             tensor = np.flip(tensor, dim)
+    return (tensor * var_adj + mean_adj).astype(np.float32)
+
+
+def _augment_params(ndims, rng):
+    """The random draws of `augment`, in its order: axis permutation, one flip decision per axis, intensity
+    shift, variance scale."""
+    perm = [int(v) for v in rng.permutation(ndims)]
+    flips = [bool(rng.uniform(0, 1.0) < .5) for _ in range(ndims)]
     mean_adj = np.float32(rng.uniform(-0.05, 0.05))
     var_adj = np.float32(rng.uniform(1, 1.05))
-    return (tensor * var_adj + mean_adj).astype(np.float32)
+    return perm, flips, mean_adj, var_adj
+
+
+def augment_device(sample, rng, out=None):
+    """`augment` for a sample already resident on the GPU: the parameters are drawn on the host exactly as
+    `augment` draws them (same generator state -> same numbers), the transform is one fused HIP kernel
+    (tem_augment_f32: transpose + flips + intensity jitter in a single pass over the volume).
+    sample: float32 CUDA tensor ([D,] H, W, 1); returns a tensor of the permuted shape."""
+    import torch
+    from .. import _lib, hip_ops as H
+    lib = H.require_gpu()
+    nd = sample.dim() - 1
+    perm, flips, mean_adj, var_adj = _augment_params(nd, rng)
+    dims = [1] * (3 - nd) + list(sample.shape[:nd])
+    p3 = list(range(3 - nd)) + [q + (3 - nd) for q in perm]
+    f3 = [False] * (3 - nd) + flips
+    src = sample.contiguous()
+    shape = tuple(sample.shape[q] for q in perm) + (1,)
+    dst = torch.empty(shape, dtype=torch.float32, device=sample.device) if out is None else out
+    _lib.check(lib.tem_augment_f32(src.data_ptr(), dims[0], dims[1], dims[2], p3[0], p3[1], p3[2], int(f3[0]), int(f3[1]),
+                                   int(f3[2]), float(var_adj), float(mean_adj), dst.data_ptr(), H.current_stream()),
+               "tem_augment_f32")
+    return dst
 
 
 class Dataset:
@@ -80,19 +110,45 @@ class Dataset:
         self.order_rng = np.random.default_rng(seed)
         self.rng = np.random.default_rng([seed, rank])
         self.device = device
+        self._dev_cache = {}
         self.rank, self.world_size = int(rank), int(world_size)
 
     def __len__(self):
         return (len(self.samples) // self.batch_size) // self.world_size     # drop_remainder=True
 
     def _emit(self, items):
+        if self.device is not None:
+            # device pipeline: samples are uploaded once (cached on the GPU for tensor datasets), augmentation is a
+            # fused HIP kernel per sample writing straight into the batch tensor
+            import torch
+            items = [self._resident(t) for t in items]
+            if not self.enable_augmentation:
+                return torch.stack(items)
+            first = augment_device(items[0], self.rng)
+            batch = torch.empty((len(items),) + tuple(first.shape), dtype=torch.float32, device=self.device)
+            batch[0].copy_(first)
+            for i, t in enumerate(items[1:], 1):
+                nd = t.dim() - 1
+                if tuple(t.shape[:nd]) != tuple(t.shape[:1]) * nd:          # non-cubic: permuted shapes differ
+                    batch[i].copy_(augment_device(t, self.rng))
+                else:
+                    augment_device(t, self.rng, out=batch[i])
+            return batch
         if self.enable_augmentation:
             items = [augment(t, self.rng) for t in items]
-        batch = np.stack(items).astype(np.float32)
-        if self.device is not None:
-            import torch
-            batch = torch.from_numpy(np.ascontiguousarray(batch)).to(self.device, non_blocking=True)
-        return batch
+        return np.stack(items).astype(np.float32)
+
+    def _resident(self, t):
+        import torch
+        if torch.is_tensor(t):
+            return t
+        key = id(t)
+        hit = self._dev_cache.get(key) if self.samples is not None else None
+        if hit is None:
+            hit = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).to(self.device)
+            if self.samples is not None:                  # tensor dataset: the reference's .cache()
+                self._dev_cache[key] = hit
+        return hit
 
     def __iter__(self):
         order = self.order_rng.permutation(len(self.samples)) if self.randomize else np.arange(len(self.samples))

@@ -30,6 +30,23 @@ def warp_tensor(tensor, rng=None):
     return out[..., None]
 
 
+def warp_tensor_device(tensor, seed=0, return_seeds=False):
+    """`warp_tensor` for a sample resident on the GPU (three HIP kernels behind tem_warp_f32: blur + mean, Philox
+    hole seeds, dilation + fill).  tensor: float32 CUDA tensor (H, W, 1) or (D, H, W, 1); the hole positions come
+    from the Philox stream of `seed`."""
+    from . import _lib, hip_ops as H
+    lib = H.require_gpu()
+    t = tensor.contiguous()
+    nd = t.dim() - 1
+    D, Hh, W = ([1] * (3 - nd) + list(t.shape[:nd]))
+    out = torch.empty_like(t)
+    seeds = torch.empty(D * Hh * W, dtype=torch.uint8, device=t.device)
+    ssum = torch.zeros(1, dtype=torch.float64, device=t.device)
+    _lib.check(lib.tem_warp_f32(t.data_ptr(), D, Hh, W, 4.0 / (128 * 128), int(seed), out.data_ptr(), seeds.data_ptr(),
+                                ssum.data_ptr(), H.current_stream()), "tem_warp_f32")
+    return (out, seeds.view(t.shape[:nd])) if return_seeds else out
+
+
 def accuracy(unwarped_orig_tensor, predicted_tensor):
     """Root-mean-squared error between two tensors (tf.keras.metrics.RootMeanSquaredError, debug.py:65-71)."""
     a = torch.as_tensor(unwarped_orig_tensor).detach().to("cpu", torch.float64)
