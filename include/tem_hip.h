@@ -130,6 +130,21 @@ int tem_conv(const tem_conv_args *a, tem_stream_t stream);
  * w_layout is ignored. */
 int tem_conv_transpose(const tem_conv_args *a, tem_stream_t stream);
 
+/* ---- bf16 mixed precision (BASELINE config 5; the reference is fp32 only, cgan.py:13-14) -------------------------
+ * Activations, gate / add views and the kernel copy are bfloat16: the `float *` fields of tem_view / tem_conv_args
+ * carry bf16 pointers, strides stay in ELEMENTS.  `w` is the layer's kernel packed [tap][co][ci] in bf16
+ * (tem_pack_weights_bf16); w_layout == TEM_W_FLIP_CO_CI reverses the taps (input-gradient of a stride-1 layer over
+ * the un-transposed copy).  Accumulation, bias, LeakyReLU / gate / dropout run in fp32; outputs are rounded to
+ * bf16 (nearest even) on store.  Same operator definition and epilogue order as tem_conv. */
+int tem_conv_bf16(const tem_conv_args *a, tem_stream_t stream);
+
+/* TEM_OK and the kernel's name (as rocprofv3 prints it) if tem_conv_bf16 accepts these arguments. */
+int tem_conv_bf16_describe(const tem_conv_args *a, char *name, int32_t name_len);
+
+/* bf16 form of tem_conv_transpose (k4 s2 only): `w` = bf16 kernel [tap][co][ci]. */
+int tem_conv_transpose_bf16(const tem_conv_args *a, tem_stream_t stream);
+int tem_conv_transpose_bf16_describe(const tem_conv_args *a, char *name, int32_t name_len);
+
 /* The shape-generic VALU implementations behind tem_conv / tem_conv_transpose, exported so
  * that tests can compare them with the LDS/MFMA-tiled kernels the dispatcher prefers. */
 int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream);

@@ -1,0 +1,131 @@
+"""bf16 mixed precision (BASELINE config 5): bf16 activations and kernel copies, fp32 accumulation on
+v_mfma_f32_16x16x32_bf16, fp32 master weights / slabs / Adam.
+
+The reference is fp32 only (cgan.py:13-14), so this mode is a build extension; its oracle is the same CPU
+restatement evaluated on the bf16-ROUNDED operands (inputs, kernels, every stored activation), compared at a
+tolerance set by bf16's 8-bit significand: outputs are rounded to bf16 on store (relative error up to 2^-9 per
+value) and the fp32 accumulation order differs from the oracle's double sums.  PARITY UNPINNED, as for fp32."""
+import numpy as np
+import pytest
+import torch
+
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 6e-3          # |hip - oracle|_max / |oracle|_max: one bf16 ulp at the top of the range is 2^-8 = 3.9e-3 (half: 2e-3)
+
+
+@pytest.fixture(scope="module")
+def H():
+    from transfer_em_amd import hip_ops
+    hip_ops.require_gpu()
+    return hip_ops
+
+
+def rb(a):
+    """Round a float32 array to bf16-representable values (nearest even)."""
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def devb(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).cuda()
+
+
+def pack(w_tap_ci_co):
+    """Operator kernel W(tap, ci, co) -> packed bf16 [tap][co][ci] (what tem_pack_weights_bf16 produces)."""
+    k = w_tap_ci_co.shape[:3]
+    ci, co = w_tap_ci_co.shape[3:]
+    return devb(np.ascontiguousarray(w_tap_ci_co.reshape(-1, ci, co).transpose(0, 2, 1)).reshape(-1))
+
+
+def rnd(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+FWD = [(1, 8, 3, 1, 0, 21), (8, 8, 3, 1, 0, 18), (8, 16, 3, 1, 0, 14), (16, 16, 3, 1, 0, 17), (16, 32, 3, 1, 0, 11),
+       (32, 32, 3, 1, 0, 10), (32, 16, 3, 1, 0, 10), (16, 1, 3, 1, 0, 19), (8, 8, 4, 2, 0, 20), (16, 16, 4, 2, 0, 15),
+       (32, 32, 4, 2, 0, 12), (8, 16, 4, 2, 1, 14), (16, 32, 4, 2, 1, 10), (32, 32, 1, 1, 0, 6), (32, 1, 1, 1, 0, 6),
+       (1, 8, 3, 1, 5, 9), (16, 16, 3, 1, 2, 13), (16, 8, 3, 1, -1, 15), (8, 1, 3, 1, 2, 12)]
+
+
+@pytest.mark.parametrize("CI,CO,k,s,pad,n", FWD)
+def test_conv_bf16_forward(H, oracle_lib, CI, CO, k, s, pad, n):
+    rng = np.random.default_rng(CI * 1000 + CO * 10 + k)
+    x = rb(rnd(rng, 2, n, n, n + 1, CI))
+    w = rb(rnd(rng, k, k, k, CI, CO) * 0.2)
+    bias = rnd(rng, CO) if CO == 1 else None
+    xin = x[:, -pad:pad, -pad:pad, -pad:pad, :] if pad < 0 else x
+    ref = oracle_lib.leaky_relu(oracle_lib.conv_fwd(xin, w, s, max(pad, 0), bias))
+    out = torch.empty(ref.shape, dtype=torch.bfloat16, device="cuda")
+    launch = H.conv_launch("t", devb(x), pack(w), out, k, s, pad, slope=0.3,
+                           bias=torch.from_numpy(bias).cuda() if bias is not None else None)
+    H.run([launch])
+    assert launch.meta["kernel"].startswith("conv_bf16_k")
+    assert rel_err(out.float().cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("CI,CO", [(16, 8), (32, 16), (8, 8), (16, 16), (32, 32)])
+def test_conv_transpose_bf16(H, oracle_lib, CI, CO):
+    """k4 s2 transposed convolution (parity-class GEMM) in bf16: shifted windows, gate + add, batch 2."""
+    rng = np.random.default_rng(CI * 3 + CO)
+    w = rb(rnd(rng, 4, 4, 4, CO, CI) * 0.1)
+    for n, pad, lo, osz in ((9, 1, 0, 18), (7, 1, 3, 9), (6, 0, 2, 11)):
+        x = rb(rnd(rng, 2, n, n, n, CI))
+        full = oracle_lib.convT_fwd(x, w, 2, pad, out_dims=(2 * n + 2 - 2 * pad,) * 3)
+        win = full[:, lo:lo + osz, lo:lo + osz, lo:lo + osz, :]
+        saved = rb(rnd(rng, *win.shape))
+        addw = rb(rnd(rng, 2, osz - 2, osz - 2, osz - 2, CO))
+        ref = win.copy()
+        ref[:, 1:-1, 1:-1, 1:-1, :] += addw
+        ref = oracle_lib.leaky_relu_grad_from_out(ref, saved)
+        out = torch.empty(ref.shape, dtype=torch.bfloat16, device="cuda")
+        launch = H.conv_launch("t", devb(x), devb(w.reshape(-1)), out, 4, 2, pad + lo, transposed=True, gate=devb(saved),
+                               add=devb(addw), add_off=1)
+        H.run([launch])
+        assert launch.meta["kernel"].startswith("convT_bf16_k")
+        assert rel_err(out.float().cpu().numpy(), ref) < TOL, (n, pad, lo, osz)
+
+
+def test_conv_bf16_dropout_mask_concat_split(H, oracle_lib):
+    """Dropout keep mask written by the bf16 transposed convolution (forward) and read by the bf16 input-gradient
+    through a concat (split 8|8 outputs, gate on the first half only) -- the same Philox bits as the oracle's."""
+    rng = np.random.default_rng(11)
+    n = 12
+    x = rb(rnd(rng, 1, n, n, n, 16))
+    w = rb(rnd(rng, 4, 4, 4, 8, 16) * 0.1)
+    shape = (1, 2 * n, 2 * n, 2 * n, 8)
+    c = oracle_lib.convT_fwd(x, w, 2, 1)
+    keep = oracle_lib.dropout_mask(shape, 42, 5, 2)
+    ref_fwd = oracle_lib.leaky_relu(c * keep.astype(np.float32) * 2)
+    out = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+    mask = torch.zeros(int(np.prod(shape)) // 8, dtype=torch.uint8, device="cuda")
+    step = torch.tensor([2], dtype=torch.int32, device="cuda")
+    H.run([H.conv_launch("t", devb(x), devb(w.reshape(-1)), out, 4, 2, 1, transposed=True, slope=0.3, dropout=(42, 5, step),
+                         keep_mask=(mask, 1))])
+    assert np.array_equal(np.unpackbits(mask.cpu().numpy(), bitorder="little").astype(bool), keep.reshape(-1))
+    assert rel_err(out.float().cpu().numpy(), ref_fwd) < TOL
+    # input-gradient of a 16 -> 16 k3 conv whose input was concat([up (dropout+lrelu), skip]): split outputs
+    g = rb(rnd(rng, 1, 2 * n - 2, 2 * n - 2, 2 * n - 2, 16))
+    wf = rb(rnd(rng, 3, 3, 3, 16, 16) * 0.1)                 # Keras forward kernel (tap, ci, co)
+    full = oracle_lib.conv_bwd_data(g, wf, (1, 2 * n, 2 * n, 2 * n, 16))
+    up = out.float().cpu().numpy()
+    ref0 = oracle_lib.leaky_relu_grad_from_out(full[..., :8], up) * keep.astype(np.float32) * 2
+    ref1 = full[..., 8:]
+    # operator kernel W(tap, ci=co_f, co=ci_f) = wf[ntap-1-tap][ci_f][co_f]: un-transposed bf16 copy + tap flip
+    res = []
+    for km in (None, (mask, 2)):
+        d0 = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+        d1 = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+        H.run([H.conv_launch("t", devb(g), devb(wf.reshape(-1)), d0, 3, 1, 2, layout=H.TEM_W_FLIP_CO_CI, out1=d1, gate=out,
+                             dropout=(42, 5, step), keep_mask=km)])
+        res.append((d0.float().cpu().numpy(), d1.float().cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert rel_err(res[0][0], ref0) < TOL and rel_err(res[0][1], ref1) < TOL
+    # concat on the input side: conv over [up | crop(skip)]
+    skip = rb(rnd(rng, 1, 2 * n + 3, 2 * n + 3, 2 * n + 3, 8))
+    cat = np.concatenate([up, skip[:, 1:-2, 1:-2, 1:-2, :]], -1)
+    ref = oracle_lib.leaky_relu(oracle_lib.conv_fwd(cat, wf))
+    o2 = torch.empty(ref.shape, dtype=torch.bfloat16, device="cuda")
+    sk = devb(skip)
+    H.run([H.conv_launch("t", out, pack(wf), o2, 3, in1=H.crop(sk, 1, 2), slope=0.3)])
+    assert rel_err(o2.float().cpu().numpy(), ref) < TOL

@@ -68,6 +68,10 @@ _SIGS = {
     "tem_conv_transpose": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_direct": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_transpose_direct": [C.POINTER(tem_conv_args), C.c_void_p],
+    "tem_conv_bf16": [C.POINTER(tem_conv_args), C.c_void_p],
+    "tem_conv_bf16_describe": [C.POINTER(tem_conv_args), C.c_char_p, C.c_int32],
+    "tem_conv_transpose_bf16": [C.POINTER(tem_conv_args), C.c_void_p],
+    "tem_conv_transpose_bf16_describe": [C.POINTER(tem_conv_args), C.c_char_p, C.c_int32],
     "tem_conv_is_tiled": [C.POINTER(tem_conv_args), C.c_int32, C.c_char_p, C.c_int32],
     "tem_bww_is_tiled": [C.POINTER(tem_bww_args), C.c_char_p, C.c_int32],
     "tem_conv_bwd_weight": [C.POINTER(tem_bww_args), C.c_void_p],

@@ -26,7 +26,7 @@ def require_gpu():
 
 def view(t):
     """tem_view of a float32 NDHWC torch tensor (any strides with unit channel stride)."""
-    assert t.dtype == torch.float32 and t.dim() == 5, (t.dtype, t.shape)
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 5, (t.dtype, t.shape)     # bf16: config-5 mode
     assert t.shape[4] == 1 or t.stride(4) == 1, "channel stride must be 1"
     v = tem_view()
     v.ptr = t.data_ptr()
@@ -126,7 +126,13 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
             assert mask.dtype == torch.uint8 and mask.is_contiguous()
             ep.keep_mask, ep.keep_mode = mask.data_ptr(), int(mode)
             keep.append(mask)
-    if transposed:
+    bf16 = in0.dtype == torch.bfloat16
+    if bf16:
+        # bf16 mixed precision (BASELINE config 5): bf16 activations / gate / add views, `w` = bf16 kernel packed
+        # [tap][co][ci] (ParamSet.theta_h / theta_ht), fp32 accumulation and epilogue (tem_conv_bf16)
+        assert w.dtype == torch.bfloat16 and out0.dtype == torch.bfloat16 and not direct
+        fn = lib.tem_conv_transpose_bf16 if transposed else lib.tem_conv_bf16
+    elif transposed:
         fn = lib.tem_conv_transpose_direct if direct else lib.tem_conv_transpose
     else:
         fn = lib.tem_conv_direct if direct else lib.tem_conv
@@ -136,7 +142,14 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
     vin, vout = in0.numel() // ci0, out0.numel() // co0
     ci, co = ci0 + ci1, co0 + co1
     namebuf = C.create_string_buffer(96)
-    tiled = (not direct) and lib.tem_conv_is_tiled(C.byref(a), int(transposed), namebuf, 96) == 1
+    if bf16:
+        rc = (lib.tem_conv_transpose_bf16_describe if transposed else lib.tem_conv_bf16_describe)(C.byref(a), namebuf, 96)
+        if rc:
+            _lib.check(rc, name + " (bf16 geometry)")
+        tiled = True
+    else:
+        tiled = (not direct) and lib.tem_conv_is_tiled(C.byref(a), int(transposed), namebuf, 96) == 1
+    esz = 2.0 if bf16 else 4.0
     if tiled or (namebuf.value and not direct and not transposed):
         kern = namebuf.value.decode()
     elif transposed:
@@ -144,7 +157,7 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
     else:
         kern = f"conv_direct_k<{ci0}, {ci1}, {co0}, {co1}, {'true' if layout == TEM_W_FLIP_CO_CI else 'false'}>"
     meta = dict(flops=2.0 * ntap * ci * co * (vin if transposed else vout),
-                bytes=4.0 * (ci * vin + co * vout + ntap * ci * co), kernel=kern)
+                bytes=esz * (ci * vin + co * vout) + 4.0 * ntap * ci * co, kernel=kern)
     return Launch(fn, (C.byref(a),), name, keep + [a], meta)
 
 
