@@ -130,21 +130,6 @@ int tem_conv(const tem_conv_args *a, tem_stream_t stream);
  * w_layout is ignored. */
 int tem_conv_transpose(const tem_conv_args *a, tem_stream_t stream);
 
-/* ---- bf16 mixed precision (BASELINE config 5; the reference is fp32 only, cgan.py:13-14) -------------------------
- * Activations, gate / add views and the kernel copy are bfloat16: the `float *` fields of tem_view / tem_conv_args
- * carry bf16 pointers, strides stay in ELEMENTS.  `w` is the layer's kernel packed [tap][co][ci] in bf16
- * (tem_pack_weights_bf16); w_layout == TEM_W_FLIP_CO_CI reverses the taps (input-gradient of a stride-1 layer over
- * the un-transposed copy).  Accumulation, bias, LeakyReLU / gate / dropout run in fp32; outputs are rounded to
- * bf16 (nearest even) on store.  Same operator definition and epilogue order as tem_conv. */
-int tem_conv_bf16(const tem_conv_args *a, tem_stream_t stream);
-
-/* TEM_OK and the kernel's name (as rocprofv3 prints it) if tem_conv_bf16 accepts these arguments. */
-int tem_conv_bf16_describe(const tem_conv_args *a, char *name, int32_t name_len);
-
-/* bf16 form of tem_conv_transpose (k4 s2 only): `w` = bf16 kernel [tap][co][ci]. */
-int tem_conv_transpose_bf16(const tem_conv_args *a, tem_stream_t stream);
-int tem_conv_transpose_bf16_describe(const tem_conv_args *a, char *name, int32_t name_len);
-
 /* The shape-generic VALU implementations behind tem_conv / tem_conv_transpose, exported so
  * that tests can compare them with the LDS/MFMA-tiled kernels the dispatcher prefers. */
 int tem_conv_direct(const tem_conv_args *a, tem_stream_t stream);
@@ -301,6 +286,49 @@ int tem_flip_transpose(const float *theta, float *theta_t, const tem_wlayer *lay
 /* g(view) = saved(view) > 0 ? g : slope * g, in place: LeakyReLU gradient gated on the saved output where no
  * convolution epilogue can carry it (gradient entering the frozen prior network, discriminator.py:62-66). */
 int tem_leaky_gate_view(const tem_view *g, const tem_view *saved, float slope, tem_stream_t stream);
+
+/* ---- bf16 mixed precision (BASELINE config 5; the reference is fp32 only, cgan.py:13-14) -------------------------
+ * Activations, gate / add views and the kernel copy are bfloat16: the `float *` fields of tem_view / tem_conv_args
+ * carry bf16 pointers, strides stay in ELEMENTS.  `w` is the layer's kernel packed [tap][co][ci] in bf16
+ * (tem_pack_weights_bf16); w_layout == TEM_W_FLIP_CO_CI reverses the taps (input-gradient of a stride-1 layer over
+ * the un-transposed copy).  Accumulation, bias, LeakyReLU / gate / dropout run in fp32; outputs are rounded to
+ * bf16 (nearest even) on store.  Same operator definition and epilogue order as tem_conv. */
+int tem_conv_bf16(const tem_conv_args *a, tem_stream_t stream);
+
+/* TEM_OK and the kernel's name (as rocprofv3 prints it) if tem_conv_bf16 accepts these arguments. */
+int tem_conv_bf16_describe(const tem_conv_args *a, char *name, int32_t name_len);
+
+/* bf16 form of tem_conv_transpose (k4 s2 only): `w` = bf16 kernel [tap][co][ci]. */
+int tem_conv_transpose_bf16(const tem_conv_args *a, tem_stream_t stream);
+int tem_conv_transpose_bf16_describe(const tem_conv_args *a, char *name, int32_t name_len);
+
+/* bf16 form of tem_conv_bwd_weight: in0 / in1 / dout are bf16 views, the partial slabs are float32 (the split-K
+ * finish, the gradient vector and Adam stay fp32).  The launch writes exactly the number of slabs that
+ * tem_conv_bwd_weight_bf16_nslab(a) returns for a->nslab = the caller's upper bound (negative: TEM_E*; `name`, if
+ * non-NULL, receives the kernel's name); pass that value back as a->nslab. */
+int tem_conv_bwd_weight_bf16(const tem_bww_args *a, tem_stream_t stream);
+int tem_conv_bwd_weight_bf16_nslab(const tem_bww_args *a, char *name, int32_t name_len);
+
+/* dst[i] = bf16(src[i]) (round to nearest even) */
+int tem_cast_f32_to_bf16(const float *src, void *dst, int64_t n, tem_stream_t stream);
+
+/* The per-step bf16 kernel copies of one network: theta_h = bf16(theta), same layout; theta_ht = every kernel of
+ * the table with its last two axes transposed ([tap][A][B] -> [tap][B][A]).  tem_conv_bf16 contracts over the LAST
+ * axis of the copy it is given: forward of a Conv layer reads theta_ht, its stride-1 input-gradient theta_h with
+ * TEM_W_FLIP_CO_CI; a ConvTranspose layer (and the input-gradient of a stride-2 Conv through
+ * tem_conv_transpose_bf16) reads theta_h, the ConvTranspose input-gradient theta_ht. */
+int tem_pack_weights_bf16(const float *theta, void *theta_h, void *theta_ht, const tem_wlayer *layers_dev,
+                          int32_t nlayers, int64_t total, tem_stream_t stream);
+
+/* bf16 forms of tem_focal_logits / tem_focal_match / tem_copy_view / tem_add_view / tem_channel_sum: bf16 views in
+ * and out, fp32 arithmetic, double loss sums. */
+int tem_focal_logits_bf16(const tem_view *z, int32_t target, float gamma, double *losses, uint32_t slot_mask,
+                          float loss_scale, const tem_view *dz, float grad_scale, tem_stream_t stream);
+int tem_focal_match_bf16(const tem_view *a, const tem_view *b, float gamma, double *losses, uint32_t slot_mask,
+                         float loss_scale, const tem_view *db, float grad_scale, tem_stream_t stream);
+int tem_copy_view_bf16(const tem_view *src, const tem_view *dst, tem_stream_t stream);
+int tem_add_view_bf16(const tem_view *src, const tem_view *dst, tem_stream_t stream);
+int tem_channel_sum_bf16(const tem_view *g, float *out, int32_t accumulate, tem_stream_t stream);
 
 /* InstanceNormalization (models/utils.py:10-38; defined there, every call site commented out at
  * models/utils.py:75-76,81-82,124-125,131): per sample and channel, over the spatial axes,

@@ -129,3 +129,89 @@ def test_conv_bf16_dropout_mask_concat_split(H, oracle_lib):
     sk = devb(skip)
     H.run([H.conv_launch("t", out, pack(wf), o2, 3, in1=H.crop(sk, 1, 2), slope=0.3)])
     assert rel_err(o2.float().cpu().numpy(), ref) < TOL
+
+
+class _P:          # minimal stand-in for a ParamSet: one layer "w"
+    def __init__(self, shape):
+        self.shapes = {"w": shape}
+        self.grad = torch.zeros(int(np.prod(shape)), dtype=torch.float32, device="cuda")
+        self.theta = self.grad
+
+    def g(self, name):
+        return self.grad
+
+
+def _bww(H, x, g, shape, k, s=1, pad=0, in1=None):
+    ps = _P(shape)
+    ws = H.GradWorkspace(ps, 1)
+    launch = H.bww_launch("t0", x, g, ws, "w", 0, k, s, pad, in1=in1)
+    H.run([launch] + ws.reduce_launches("t"))
+    return ps.grad.cpu().numpy().reshape(shape), launch.meta["kernel"]
+
+
+BWW = [(1, 8, 3, 1, 0, 20), (8, 8, 3, 1, 0, 14), (8, 16, 3, 1, 0, 12), (16, 8, 3, 1, 2, 11), (16, 16, 3, 1, 0, 19),
+       (16, 32, 3, 1, 0, 10), (32, 16, 3, 1, 0, 10), (32, 32, 3, 1, 0, 9), (16, 1, 3, 1, 0, 13), (8, 8, 4, 2, 0, 18),
+       (16, 16, 4, 2, 0, 13), (32, 32, 4, 2, 0, 10), (8, 16, 4, 2, 1, 14), (16, 32, 4, 2, 1, 10), (32, 32, 1, 1, 0, 6),
+       (32, 1, 1, 1, 0, 6), (1, 8, 3, 1, 4, 9), (16, 16, 3, 1, 0, 37)]
+
+
+@pytest.mark.parametrize("CI,CO,k,s,pad,n", BWW)
+def test_kernel_gradient_bf16(H, oracle_lib, CI, CO, k, s, pad, n):
+    """bf16 activations and gradients in, fp32 slabs out (ds_read_b64_tr_b16 fragments, v_mfma_f32_16x16x16_bf16):
+    the sum runs over up to ~10^5 voxels in fp32, so the error is the fp32 summation order, not bf16."""
+    rng = np.random.default_rng(CI * 7 + CO + k)
+    x = rb(rnd(rng, 2, n, n, n + 1, CI))
+    o = [(d + 2 * pad - k) // s + 1 for d in (n, n, n + 1)]
+    g = rb(rnd(rng, 2, o[0], o[1], o[2], CO))
+    ref = oracle_lib.conv_bwd_weight(x, g, (k, k, k), s, pad)
+    got, kern = _bww(H, devb(x), devb(g), ref.shape, k, s, pad)
+    assert kern.startswith("bww_bf16_k"), kern
+    assert rel_err(got, ref) < 2e-5, kern
+
+
+def test_kernel_gradient_bf16_concat_and_transposed_layer(H, oracle_lib):
+    rng = np.random.default_rng(11)
+    up, skip = rb(rnd(rng, 1, 9, 9, 9, 8)), rb(rnd(rng, 1, 12, 12, 12, 8))
+    g = rb(rnd(rng, 1, 7, 7, 7, 16))
+    ref = oracle_lib.conv_bwd_weight(np.concatenate([up, skip[:, 1:10, 1:10, 1:10]], -1), g, (3, 3, 3))
+    sk = devb(skip)
+    got, _ = _bww(H, devb(up), devb(g), ref.shape, 3, in1=H.crop(sk, 1, 2))
+    assert rel_err(got, ref) < 2e-5
+    x = rb(rnd(rng, 1, 6, 6, 6, 16))
+    gy = rb(rnd(rng, 1, 12, 12, 12, 8))
+    refT = oracle_lib.convT_bwd_weight(x, gy, (4, 4, 4), 2, 1)       # Keras layout (tap, CO, CI): roles swapped
+    got, _ = _bww(H, devb(gy), devb(x), refT.shape, 4, 2, 1)
+    assert rel_err(got, refT) < 2e-5
+
+
+def test_pack_weights_and_elementwise_bf16(H, oracle_lib):
+    from transfer_em_amd.models.params import ParamSet
+    from collections import OrderedDict
+    shapes = OrderedDict([("a", (3, 3, 3, 8, 16)), ("b", (4, 4, 4, 16, 8)), ("b_bias", (1,))])
+    P = ParamSet(shapes, "cuda", seed=3)
+    H.run([P.pack_bf16_launch()])
+    th = P.to_dict("theta")
+    for name in ("a", "b"):
+        w = th[name]
+        assert np.array_equal(P.wh(name).float().cpu().numpy().reshape(w.shape), rb(w))
+        wt = np.ascontiguousarray(np.swapaxes(w, 3, 4))
+        assert np.array_equal(P.wht(name).float().cpu().numpy().reshape(wt.shape), rb(wt))
+    rng = np.random.default_rng(5)
+    z = rb(rnd(rng, 2, 4, 4, 4, 1) * 3)
+    losses = torch.zeros(8, dtype=torch.float64, device="cuda")
+    l_ref, g_ref = oracle_lib.focal_logits(z, 1, 2.0)
+    dz = torch.empty(z.shape, dtype=torch.bfloat16, device="cuda")
+    H.run([H.focal_logits_launch("t", devb(z), 1, 2.0, losses, 0b1, 2.0, dz, 3.0)])
+    assert abs(losses.cpu().numpy()[0] - 2 * l_ref) < 1e-6 * abs(2 * l_ref)
+    assert rel_err(dz.float().cpu().numpy(), 3 * g_ref) < TOL
+    a = rb(rnd(rng, 1, 9, 9, 9, 1))
+    b = rb(a + rnd(rng, 1, 9, 9, 9, 1) * 0.7)
+    l_ref, g_ref = oracle_lib.focal_prob_match(a, b, 2.0)
+    db = torch.empty(a.shape, dtype=torch.bfloat16, device="cuda")
+    losses.zero_()
+    H.run([H.focal_match_launch("t", devb(a), devb(b), 2.0, losses, 0b10, 4.0, db, 4.0)])
+    assert abs(losses.cpu().numpy()[1] - 4 * l_ref) < 2e-6 * abs(4 * l_ref)
+    assert rel_err(db.float().cpu().numpy(), 4 * g_ref) < TOL
+    u, v = devb(a), devb(b)
+    H.run([H.copy_view_launch("t", u, v, add=True)])
+    assert np.array_equal(v.float().cpu().numpy(), rb(a + b))

@@ -72,6 +72,15 @@ _SIGS = {
     "tem_conv_bf16_describe": [C.POINTER(tem_conv_args), C.c_char_p, C.c_int32],
     "tem_conv_transpose_bf16": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_transpose_bf16_describe": [C.POINTER(tem_conv_args), C.c_char_p, C.c_int32],
+    "tem_conv_bwd_weight_bf16": [C.POINTER(tem_bww_args), C.c_void_p],
+    "tem_conv_bwd_weight_bf16_nslab": [C.POINTER(tem_bww_args), C.c_char_p, C.c_int32],
+    "tem_cast_f32_to_bf16": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "tem_pack_weights_bf16": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p],
+    "tem_focal_logits_bf16": [_VP, C.c_int32, C.c_float, C.c_void_p, C.c_uint32, C.c_float, _VP, C.c_float, C.c_void_p],
+    "tem_focal_match_bf16": [_VP, _VP, C.c_float, C.c_void_p, C.c_uint32, C.c_float, _VP, C.c_float, C.c_void_p],
+    "tem_copy_view_bf16": [_VP, _VP, C.c_void_p],
+    "tem_add_view_bf16": [_VP, _VP, C.c_void_p],
+    "tem_channel_sum_bf16": [_VP, C.c_void_p, C.c_int32, C.c_void_p],
     "tem_conv_is_tiled": [C.POINTER(tem_conv_args), C.c_int32, C.c_char_p, C.c_int32],
     "tem_bww_is_tiled": [C.POINTER(tem_bww_args), C.c_char_p, C.c_int32],
     "tem_conv_bwd_weight": [C.POINTER(tem_bww_args), C.c_void_p],

@@ -1,0 +1,330 @@
+// bww_bf16.hip -- kernel gradient for the bf16 mixed-precision mode (BASELINE config 5): bf16 activations and
+// gradients in, fp32 accumulation on the matrix cores, fp32 partial slabs out (the split-K finish, the gradient
+// vector and Adam stay fp32 -- "fp32 master weights and accumulators").
+//
+//   dW[(tap,ci)][co] = sum over output voxels o of  X[o*S + tap - P][ci] * G[o][co]
+//
+// GEMM with M = (tap,ci) rows, N = co and K = voxels.  Both operands are "K-major" (a lane needs consecutive VOXELS
+// of one channel) while memory and LDS are channels-last: ds_read_b64_tr_b16 -- the transposing LDS read of gfx950 --
+// delivers exactly that: per 16-lane group a [4 voxels][16 channels] block, column-major, so one read per operand
+// feeds v_mfma_f32_16x16x16_bf16 (k = 4 voxels per lane group, 16 per instruction) straight from the channels-last
+// image.  A workgroup owns (n, a run of output planes, a band of output rows) and ALL accumulator tiles of its row
+// group; they live in registers for the whole run, so each workgroup writes one deterministic fp32 slab
+// (tem_reduce_slabs_multi finishes the sum, as in fp32 mode).  C_in == 1 (first layers, and the swapped form of the
+// C_out == 1 layer) takes its A fragments with plain 2-byte reads: 4 consecutive voxels of one tap are contiguous.
+#include "tem_common.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace bww_bf16 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// x / d for 0 <= x < 2^31 with magic = ceil(2^32 / d) (d == 1: the magic does not fit 32 bits)
+__device__ __forceinline__ int fdiv(int x, int d, uint32_t magic) { return d == 1 ? x : (int)__umulhi((uint32_t)x, magic); }
+
+struct Dev {
+  const u16 *in0, *in1;
+  int32_t i0N, i0D, i0H, i0W, i1N, i1D, i1H, i1W, C0;
+  int32_t D, H, W;
+  const u16 *g;
+  int32_t gN, gD, gH, gW, OD, OH, OW, P;
+  float *slabs;
+  int64_t slab_stride;
+  int32_t TY, nband, zsegs, zper;
+  int32_t rows, colsR, colsA, OWp;            // X patch rows, loaded / allocated columns; G row length padded to 16
+  uint32_t magicColsR, magicPlaneR, magicOW;
+};
+
+template <int CI, int CO, int K, int S, int PFX, int PFG, int MTG>
+__global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
+  constexpr int NTAP = K * K * K, ROWS = NTAP * CI, MT = (ROWS + 15) / 16, NT = (CO + 15) / 16;
+  constexpr int WPN = 4 / NT;                              // waves per n-tile
+  constexpr int TPW = (MTG + WPN - 1) / WPN;               // accumulator tiles per wave
+  constexpr int PITCH = CI >= 8 ? CI + 4 : 1;              // X voxel pitch (bf16 elements; 8-byte aligned)
+  constexpr int GP = CO + 4;                               // G voxel pitch
+  constexpr int CPX = CI >= 8 ? CI / 8 : 1, CPG = CO / 8;  // 16-byte chunks per voxel
+  static_assert(CO % 8 == 0 && (CI == 1 || CI % 8 == 0) && 4 % NT == 0, "channel counts");
+  extern __shared__ __attribute__((aligned(16))) u16 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g4 = lane >> 4, q = m >> 2, pq = m & 3;
+  const int planeA = p.rows * p.colsA;
+  u16 *Xs = lds;
+  const int x_elems = (K * planeA * PITCH + 7) & ~7;
+  u16 *Gs = lds + x_elems;
+  const int g_elems = p.TY * p.OWp * GP + 16;
+
+  int b = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int zseg = b % p.zsegs; b /= p.zsegs;
+  const int band = b % p.nband;
+  const int n = b / p.nband;
+  const int grp = blockIdx.y;
+  const int oy0 = band * p.TY, TYr = min(p.TY, p.OH - oy0);
+  const int oz0 = zseg * p.zper, oz1 = min(p.OD, oz0 + p.zper);
+
+  // zero the whole image once: padded columns / voxels are never written again and must stay zero (G) / finite (X)
+  for (int i = tid; i < (x_elems + g_elems + 7) / 8; i += 256) reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  // ---- this wave's accumulator tiles: n-tile fixed, m-tiles grp*MTG + (wave/NT) + j*WPN
+  const int nt = wave % NT;
+  int aconst[TPW];
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int mt = min(grp * MTG + wave / NT + j * WPN, MT - 1);       // surplus tiles recompute the last one, never stored
+    if constexpr (CI >= 8) {
+      const int m0 = min(16 * mt + 4 * pq, ROWS - 4);                   // this lane addresses rows m0..m0+3 (4 channels of one tap)
+      const int tap = m0 / CI, ci0 = m0 - tap * CI;
+      const int dz = tap / (K * K), rem = tap - dz * (K * K), dy = rem / K, dx = rem - dy * K;
+      aconst[j] = ((dz * p.rows + dy) * p.colsA + dx) * PITCH + ci0 + (4 * g4 + q) * S * PITCH;
+    } else {
+      const int tap = min(16 * mt + m, NTAP - 1);                       // row m of the tile = one tap
+      const int dz = tap / (K * K), rem = tap - dz * (K * K), dy = rem / K, dx = rem - dy * K;
+      aconst[j] = (dz * p.rows + dy) * p.colsA + dx + 4 * g4;
+    }
+    acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int bconst = (4 * g4 + q) * GP + min(nt * 16 + 4 * pq, CO + 4 - 4);
+
+  const int iy0 = oy0 * S - p.P;
+  const int nk = p.OWp >> 4;
+  for (int oz = oz0; oz < oz1; ++oz) {
+    __syncthreads();                                         // zero fill done / previous plane's readers done
+    // ---- X patch (K planes) and G rows of this output plane: all loads first, then the LDS writes
+    {
+      const int iz0 = oz * S - p.P;
+      if constexpr (CI >= 8) {
+        const int totalX = K * p.rows * p.colsR * CPX;
+        uint4 pf[PFX];
+#pragma unroll
+        for (int i = 0; i < PFX; ++i) {
+          const int id = tid + i * 256;
+          const int vox = id / CPX, c = (id - vox * CPX) * 8;
+          const int pl = fdiv(vox, p.rows * p.colsR, p.magicPlaneR), r2 = vox - pl * (p.rows * p.colsR);
+          const int r = fdiv(r2, p.colsR, p.magicColsR), cx = r2 - r * p.colsR;
+          const int iz = iz0 + pl, iy = iy0 + r, ix = cx - p.P;
+          const bool ok = id < totalX && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          const u16 *src = c < p.C0 ? p.in0 + (n * p.i0N + iz * p.i0D + iy * p.i0H + ix * p.i0W + c)
+                                    : p.in1 + (n * p.i1N + iz * p.i1D + iy * p.i1H + ix * p.i1W + (c - p.C0));
+          pf[i] = ok ? *reinterpret_cast<const uint4 *>(src) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < PFX; ++i) {
+          const int id = tid + i * 256;
+          if (id < totalX) {
+            const int vox = id / CPX, c = (id - vox * CPX) * 8;
+            const int pl = fdiv(vox, p.rows * p.colsR, p.magicPlaneR), r2 = vox - pl * (p.rows * p.colsR);
+            const int r = fdiv(r2, p.colsR, p.magicColsR), cx = r2 - r * p.colsR;
+            u16 *d = Xs + ((pl * p.rows + r) * p.colsA + cx) * PITCH + c;       // 8-byte aligned
+            *reinterpret_cast<uint2 *>(d) = make_uint2(pf[i].x, pf[i].y);
+            *reinterpret_cast<uint2 *>(d + 4) = make_uint2(pf[i].z, pf[i].w);
+          }
+        }
+      } else {
+        const int totalX = K * p.rows * p.colsR;
+        u16 pf[PFX];
+#pragma unroll
+        for (int i = 0; i < PFX; ++i) {
+          const int id = tid + i * 256;
+          const int pl = fdiv(id, p.rows * p.colsR, p.magicPlaneR), r2 = id - pl * (p.rows * p.colsR);
+          const int r = fdiv(r2, p.colsR, p.magicColsR), cx = r2 - r * p.colsR;
+          const int iz = iz0 + pl, iy = iy0 + r, ix = cx - p.P;
+          const bool ok = id < totalX && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          pf[i] = ok ? p.in0[n * p.i0N + iz * p.i0D + iy * p.i0H + ix * p.i0W] : (u16)0;
+        }
+#pragma unroll
+        for (int i = 0; i < PFX; ++i) {
+          const int id = tid + i * 256;
+          if (id < totalX) {
+            const int pl = fdiv(id, p.rows * p.colsR, p.magicPlaneR), r2 = id - pl * (p.rows * p.colsR);
+            const int r = fdiv(r2, p.colsR, p.magicColsR), cx = r2 - r * p.colsR;
+            Xs[(pl * p.rows + r) * p.colsA + cx] = pf[i];
+          }
+        }
+      }
+      const int totalG = TYr * p.OW * CPG;
+      uint4 pg[PFG];
+#pragma unroll
+      for (int i = 0; i < PFG; ++i) {
+        const int id = tid + i * 256;
+        const int vox = id / CPG, c = (id - vox * CPG) * 8;
+        const int r = fdiv(vox, p.OW, p.magicOW), x = vox - r * p.OW;
+        pg[i] = id < totalG ? *reinterpret_cast<const uint4 *>(p.g + (n * p.gN + oz * p.gD + (oy0 + r) * p.gH + x * p.gW + c))
+                            : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int i = 0; i < PFG; ++i) {
+        const int id = tid + i * 256;
+        if (id < totalG) {
+          const int vox = id / CPG, c = (id - vox * CPG) * 8;
+          const int r = fdiv(vox, p.OW, p.magicOW), x = vox - r * p.OW;
+          u16 *d = Gs + (r * p.OWp + x) * GP + c;
+          *reinterpret_cast<uint2 *>(d) = make_uint2(pg[i].x, pg[i].y);
+          *reinterpret_cast<uint2 *>(d + 4) = make_uint2(pg[i].z, pg[i].w);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- k-blocks of 16 voxels along x, row by row
+    for (int r = 0; r < TYr; ++r) {
+      const u16 *xr = Xs + r * S * p.colsA * PITCH;
+      const u16 *gr = Gs + r * p.OWp * GP + bconst;
+      for (int kb = 0; kb < nk; ++kb) {
+        const s16x4 bfrag = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(gr + kb * 16 * GP));
+        s16x4 afrag[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          if constexpr (CI >= 8) {
+            afrag[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(xr + aconst[j] + kb * 16 * S * PITCH));
+          } else {
+            const u16 *s = xr + aconst[j] + kb * 16;
+            afrag[j] = s16x4{(short)s[0], (short)s[1], (short)s[2], (short)s[3]};
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afrag[j], bfrag, acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- one partial slab per workgroup column (grid.x); row groups (grid.y) write disjoint rows of it
+  float *slab = p.slabs + (int64_t)blockIdx.x * p.slab_stride;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int mtl = wave / NT + j * WPN, mt = grp * MTG + mtl;
+    if (mtl < MTG && mt < MT) {
+      const int co = nt * 16 + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + g4 * 4 + r;              // C/D map: row = 4*(lane>>4)+reg, col = lane&15
+        if (row < ROWS && co < CO) slab[(int64_t)row * CO + co] = acc[j][r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static uint32_t magic_for(int d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
+static thread_local char *g_name = nullptr;
+static thread_local int g_name_len = 0;
+
+template <int CI, int CO, int K, int S, int PFX, int PFG, int MTG>
+int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
+  constexpr int NTAP = K * K * K, MT = (NTAP * CI + 15) / 16;
+  constexpr int PITCH = CI >= 8 ? CI + 4 : 1, GP = CO + 4, CPX = CI >= 8 ? CI / 8 : 1, CPG = CO / 8;
+  p.OWp = (p.OW + 15) & ~15;
+  p.colsR = (p.OW - 1) * S + K;
+  p.colsA = (p.OWp - 1) * S + K + 4;                      // the last k-block reads up to OWp voxels (+ C_in == 1: 4-voxel reads)
+  int TY = 0;
+  size_t lds_bytes = 0;
+  for (int ty = 1; ty <= 8 && ty <= p.OH; ++ty) {
+    const int rows = (ty - 1) * S + K;
+    const size_t xel = (((size_t)K * rows * p.colsA * PITCH) + 7) & ~(size_t)7, gel = (size_t)ty * p.OWp * GP + 16;
+    const size_t bytes = ((xel + gel) * 2 + 15) & ~(size_t)15;
+    if ((size_t)K * rows * p.colsR * CPX > (size_t)PFX * 256 || (size_t)ty * p.OW * CPG > (size_t)PFG * 256 || bytes > 72 * 1024) break;
+    TY = ty; lds_bytes = bytes;
+  }
+  if (TY < 1) return TEM_EUNSUPPORTED;
+  p.TY = TY; p.rows = (TY - 1) * S + K;
+  p.nband = (p.OH + TY - 1) / TY;
+  const int cols = N * p.nband;
+  int want = max_slabs < 512 ? max_slabs : 512;            // ~2 workgroups per CU
+  int zsegs = want / cols;
+  if (zsegs < 1) zsegs = 1;
+  if (zsegs > p.OD) zsegs = p.OD;
+  p.zper = (p.OD + zsegs - 1) / zsegs;
+  p.zsegs = (p.OD + p.zper - 1) / p.zper;
+  const int nblocks = cols * p.zsegs;
+  if (nblocks > max_slabs) return TEM_EUNSUPPORTED;
+  if (nslab_out) *nslab_out = nblocks;
+  p.magicColsR = magic_for(p.colsR);
+  p.magicPlaneR = magic_for(p.rows * p.colsR);
+  p.magicOW = magic_for(p.OW);
+  if (dry) {
+    if (g_name) snprintf(g_name, g_name_len, "bww_bf16_k<%d, %d, %d, %d, %d, %d, %d>", CI, CO, K, S, PFX, PFG, MTG);
+    return TEM_OK;
+  }
+  auto kern = bww_bf16_k<CI, CO, K, S, PFX, PFG, MTG>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  constexpr int NGRP = (MT + MTG - 1) / MTG;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, NGRP), dim3(256), lds_bytes, st, p);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
+  const tem_view &i0 = a->in0, &g = a->dout;
+  if (!(a->kd == a->kh && a->kh == a->kw && a->sd == a->sh && a->sh == a->sw && a->pd == a->ph && a->ph == a->pw))
+    return TEM_EUNSUPPORTED;
+  if (g.N != i0.N) return TEM_ESHAPE;
+  auto U = [](const float *q) { return reinterpret_cast<const u16 *>(q); };
+  auto span_ok = [](const tem_view &v) {
+    int64_t span = (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH + (int64_t)(v.W - 1) * v.sW + v.C;
+    return span < ((int64_t)1 << 31);
+  };
+  auto al16 = [](const tem_view &v) {
+    return v.C % 8 != 0 || (((uintptr_t)v.ptr & 15) == 0 && v.sW % 8 == 0 && v.sH % 8 == 0 && v.sD % 8 == 0 && v.sN % 8 == 0);
+  };
+  if (!span_ok(i0) || !span_ok(g) || !al16(i0) || !al16(g) || g.C % 8) return TEM_EUNSUPPORTED;
+  Dev p{};
+  p.in0 = U(i0.ptr); p.i0N = (int)i0.sN; p.i0D = (int)i0.sD; p.i0H = (int)i0.sH; p.i0W = (int)i0.sW; p.C0 = i0.C;
+  p.in1 = p.in0; p.i1N = p.i0N; p.i1D = p.i0D; p.i1H = p.i0H; p.i1W = p.i0W;
+  int CI = i0.C;
+  if (a->in1.ptr) {
+    const tem_view &i1 = a->in1;
+    if (i1.N != i0.N || i1.D != i0.D || i1.H != i0.H || i1.W != i0.W) return TEM_ESHAPE;
+    if (!span_ok(i1) || !al16(i1) || i0.C % 8 || i1.C % 8) return TEM_EUNSUPPORTED;
+    p.in1 = U(i1.ptr); p.i1N = (int)i1.sN; p.i1D = (int)i1.sD; p.i1H = (int)i1.sH; p.i1W = (int)i1.sW;
+    CI += i1.C;
+  }
+  p.D = i0.D; p.H = i0.H; p.W = i0.W;
+  p.g = U(g.ptr); p.gN = (int)g.sN; p.gD = (int)g.sD; p.gH = (int)g.sH; p.gW = (int)g.sW;
+  p.OD = g.D; p.OH = g.H; p.OW = g.W; p.P = a->pd;
+  p.slabs = a->slabs;
+  const int CO = g.C, K = a->kd, S = a->sd, N = i0.N;
+  p.slab_stride = a->slab_stride ? a->slab_stride : (int64_t)K * K * K * CI * CO;
+  const int max_slabs = a->nslab;
+#define BW(ci, co, k, s, pfx, pfg, mtg) \
+  if (CI == ci && CO == co && K == k && S == s) return run<ci, co, k, s, pfx, pfg, mtg>(p, N, max_slabs, st, dry, nslab_out);
+  //  CI  CO  K  S  X-chunks  G-chunks  m-tiles per row group (all of them unless the accumulators would not fit)
+  BW(1, 8, 3, 1, 12, 4, 2)  BW(1, 16, 3, 1, 12, 4, 2)
+  BW(8, 8, 3, 1, 12, 4, 14) BW(8, 16, 3, 1, 12, 4, 14) BW(16, 8, 3, 1, 12, 4, 27) BW(16, 16, 3, 1, 12, 4, 27)
+  BW(16, 32, 3, 1, 12, 4, 27) BW(32, 16, 3, 1, 12, 4, 54) BW(32, 32, 3, 1, 12, 4, 27)
+  BW(8, 8, 4, 2, 12, 4, 32) BW(16, 16, 4, 2, 12, 4, 64) BW(8, 16, 4, 2, 12, 4, 32) BW(16, 32, 4, 2, 12, 4, 32)
+  BW(32, 32, 4, 2, 12, 4, 32)
+  BW(32, 32, 1, 1, 12, 4, 2) BW(1, 32, 1, 1, 12, 4, 1)      // 1x1 head; C_out == 1 in the swapped form
+#undef BW
+  return TEM_EUNSUPPORTED;
+}
+
+}  // namespace bww_bf16
+
+// bf16 mode of tem_conv_bwd_weight: in0 / in1 / dout are bf16 views, the partial slabs stay float32.
+// The launch writes exactly tem_conv_bwd_weight_bf16_nslab(a) slabs.
+extern "C" int tem_conv_bwd_weight_bf16(const tem_bww_args *a, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout) || !a->slabs || a->nslab < 1 || a->accumulate) return TEM_EINVAL;
+  int n = 0;
+  int rc = bww_bf16::dispatch(a, nullptr, true, &n);
+  if (rc != TEM_OK) return rc;
+  if (n != a->nslab) return TEM_EINVAL;                    // size the workspace with tem_conv_bwd_weight_bf16_nslab
+  return bww_bf16::dispatch(a, (hipStream_t)stream, false, nullptr);
+}
+
+extern "C" int tem_conv_bwd_weight_bf16_nslab(const tem_bww_args *a, char *name, int32_t name_len) {
+  if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout) || a->nslab < 1) return TEM_EINVAL;
+  int n = 0;
+  bww_bf16::g_name = name; bww_bf16::g_name_len = name_len;
+  int rc = bww_bf16::dispatch(a, nullptr, true, &n);
+  bww_bf16::g_name = nullptr;
+  return rc == TEM_OK ? n : rc;
+}

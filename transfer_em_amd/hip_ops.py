@@ -240,7 +240,12 @@ class GradWorkspace:
 def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=None):
     """Kernel-gradient launch of `layer` into its slab set `call` of GradWorkspace `ws`."""
     lib = _lib.load()
-    if is3d and dout.shape[4] == 1 and in1 is None and s == 1 and p == 0 and k == 3 and in0.shape[4] % 16 == 0:
+    bf16 = in0.dtype == torch.bfloat16
+    if bf16 and dout.shape[4] == 1 and in1 is None and s == 1 and p == 0:
+        # bf16 mode: every C_out == 1 layer (3x3x3 last conv, 1x1 head) runs in the swapped form below
+        ws.flip_rows[layer] = in0.shape[4]
+        in0, dout, p = dout, in0, k - 1
+    elif is3d and dout.shape[4] == 1 and in1 is None and s == 1 and p == 0 and k == 3 and in0.shape[4] % 16 == 0:
         # C_out == 1 (generator.py:110): a 1-wide N would waste 15/16 of every MFMA.  Swap the roles:
         #   dW[tap][ci] = sum_v X[v+tap][ci] g[v] = sum_v' g[v' - tap] X[v'][ci]
         # i.e. the kernel gradient of a pad-(k-1) conv with input g (1 channel) and "gradient" X, whose
@@ -257,7 +262,8 @@ def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=
     a.sd, a.sh, a.sw = _s3(s, is3d)
     a.pd, a.ph, a.pw = _p3(p, is3d)
     a.nslab = MAX_SLABS
-    n = lib.tem_conv_bwd_weight_nslab(C.byref(a))
+    namebuf = C.create_string_buffer(96)
+    n = lib.tem_conv_bwd_weight_bf16_nslab(C.byref(a), namebuf, 96) if bf16 else lib.tem_conv_bwd_weight_nslab(C.byref(a))
     if n < 1:
         _lib.check(n, name + " (nslab query)")
     ws.request(layer, call, n, a)           # a.slabs is patched by ws.finalize() (before the first run)
@@ -269,7 +275,10 @@ def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=
     co = dout.shape[4]
     ntap = a.kd * a.kh * a.kw
     vin, vout = in0.numel() // in0.shape[4], dout.numel() // co
-    namebuf = C.create_string_buffer(96)
+    if bf16:
+        meta = dict(flops=2.0 * ntap * ci * co * vout, bytes=2.0 * (ci * vin + co * vout) + 4.0 * ntap * ci * co,
+                    kernel=namebuf.value.decode())
+        return Launch(lib.tem_conv_bwd_weight_bf16, (C.byref(a),), name, keep + [a], meta)
     tiled = lib.tem_bww_is_tiled(C.byref(a), namebuf, 96) == 1
     mt = 6 if ci >= 32 else (3 if ci >= 16 else 2)
     meta = dict(flops=2.0 * ntap * ci * co * vout, bytes=4.0 * (ci * vin + co * vout + ntap * ci * co),
@@ -293,7 +302,8 @@ def bias_grad_launch(name, g, ws, layer, call):
     """Bias gradient (sum over voxels) written into slab 0 of (layer, call) of a GradWorkspace."""
     lib = _lib.load()
     v = view(g)
-    launch = Launch(lib.tem_channel_sum, (C.byref(v), None, 0), name, [g, v, ws])
+    fn = lib.tem_channel_sum_bf16 if g.dtype == torch.bfloat16 else lib.tem_channel_sum
+    launch = Launch(fn, (C.byref(v), None, 0), name, [g, v, ws])
     ws.request(layer, call, 1, patch=lambda ptr: setattr(launch, "args", (C.byref(v), ptr, 0)))
     return launch
 
@@ -302,7 +312,8 @@ def focal_logits_launch(name, z, target, gamma, losses, slot_mask, loss_scale, d
     lib = _lib.load()
     vz = view(z)
     vd = view(dz) if dz is not None else tem_view()
-    return Launch(lib.tem_focal_logits, (C.byref(vz), target, gamma, losses.data_ptr(), slot_mask, loss_scale,
+    fn = lib.tem_focal_logits_bf16 if z.dtype == torch.bfloat16 else lib.tem_focal_logits
+    return Launch(fn, (C.byref(vz), target, gamma, losses.data_ptr(), slot_mask, loss_scale,
                                          C.byref(vd), grad_scale), name, [z, dz, losses, vz, vd])
 
 
@@ -310,7 +321,8 @@ def focal_match_launch(name, a, b, gamma, losses, slot_mask, loss_scale, db=None
     lib = _lib.load()
     va, vb = view(a), view(b)
     vd = view(db) if db is not None else tem_view()
-    return Launch(lib.tem_focal_match, (C.byref(va), C.byref(vb), gamma, losses.data_ptr(), slot_mask, loss_scale,
+    fn = lib.tem_focal_match_bf16 if a.dtype == torch.bfloat16 else lib.tem_focal_match
+    return Launch(fn, (C.byref(va), C.byref(vb), gamma, losses.data_ptr(), slot_mask, loss_scale,
                                         C.byref(vd), grad_scale), name, [a, b, db, losses, va, vb, vd])
 
 
@@ -336,7 +348,10 @@ def fill_launch(name, t, value=0.0):
 def copy_view_launch(name, src, dst, add=False):
     lib = _lib.load()
     vs, vd = view(src), view(dst)
-    fn = lib.tem_add_view if add else lib.tem_copy_view
+    if src.dtype == torch.bfloat16:
+        fn = lib.tem_add_view_bf16 if add else lib.tem_copy_view_bf16
+    else:
+        fn = lib.tem_add_view if add else lib.tem_copy_view
     return Launch(fn, (C.byref(vs), C.byref(vd)), name, [src, dst, vs, vd])
 
 
@@ -345,6 +360,20 @@ def flip_transpose_launch(name, theta, theta_t, table_dev, nlayers):
     lib = _lib.load()
     return Launch(lib.tem_flip_transpose, (theta.data_ptr(), theta_t.data_ptr(), table_dev.data_ptr(), nlayers,
                                            theta.numel()), name, [theta, theta_t, table_dev])
+
+
+def pack_weights_launch(name, theta, theta_h, theta_ht, table_dev, nlayers):
+    """theta_h / theta_ht := the per-step bf16 kernel copies of one network (tem_pack_weights_bf16)."""
+    lib = _lib.load()
+    return Launch(lib.tem_pack_weights_bf16, (theta.data_ptr(), theta_h.data_ptr(), theta_ht.data_ptr(), table_dev.data_ptr(),
+                                              nlayers, theta.numel()), name, [theta, theta_h, theta_ht, table_dev])
+
+
+def cast_bf16_launch(name, src, dst):
+    """dst (bf16) := src (float32), both dense."""
+    lib = _lib.load()
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() and dst.dtype == torch.bfloat16
+    return Launch(lib.tem_cast_f32_to_bf16, (src.data_ptr(), dst.data_ptr(), src.numel()), name, [src, dst])
 
 
 def leaky_gate_launch(name, g, saved, slope):

@@ -37,6 +37,7 @@ class ParamSet:
             host[i] = (o_, nt, ci, co, 0)
         self._wtable = torch.from_numpy(host.view(np.uint8).copy()).to(self.device)
         self._nlayers = len(tab)
+        self.theta_h = self.theta_ht = None          # bf16 kernel copies (mixed precision), made on demand
         self.initialize(seed)
 
     def initialize(self, seed=None):
@@ -64,6 +65,26 @@ class ParamSet:
         """1-D slice of theta_t: kernel `name` with reversed taps and [co][ci] blocks (see __init__)."""
         o = self.offsets[name]
         return self.theta_t[o:o + int(np.prod(self.shapes[name]))]
+
+    def enable_bf16(self):
+        """Allocate the per-step bf16 kernel copies: theta_h (same layout) and theta_ht (last two axes of every
+        kernel transposed); fp32 `theta` stays the master copy the optimizer updates."""
+        if self.theta_h is None:
+            self.theta_h = torch.zeros(self.count, dtype=torch.bfloat16, device=self.device)
+            self.theta_ht = torch.zeros(self.count, dtype=torch.bfloat16, device=self.device)
+
+    def wh(self, name):
+        o = self.offsets[name]
+        return self.theta_h[o:o + int(np.prod(self.shapes[name]))]
+
+    def wht(self, name):
+        o = self.offsets[name]
+        return self.theta_ht[o:o + int(np.prod(self.shapes[name]))]
+
+    def pack_bf16_launch(self, name="pack_bf16"):
+        from .. import hip_ops as H
+        self.enable_bf16()
+        return H.pack_weights_launch(name, self.theta, self.theta_h, self.theta_ht, self._wtable, self._nlayers)
 
     def flip_transpose_launch(self, name="flip_transpose"):
         from .. import hip_ops as H
