@@ -23,6 +23,38 @@ def dropout_site(call_id, block):
     return call_id * 4 + block
 
 
+# --------------------------------------------------------------------------- storage precision
+# The reference computes in float32 only (cgan.py:13-14).  The build's bf16 mixed-precision mode (BASELINE config 5)
+# stores every activation, every back-propagated gradient and a per-step copy of the kernels in bfloat16 while
+# accumulating, reducing kernel gradients and running Adam in fp32.  `precision("bf16")` makes this restatement round
+# at exactly those storage points (nearest even), so the HIP path has an oracle for that mode too; the default is
+# the identity and leaves the fp32 restatement bit for bit unchanged.
+import contextlib
+
+_Q = lambda t: t          # stored activation / gradient
+_QW = lambda w: w         # kernel copy read by the convolutions (the fp32 master feeds Adam only)
+
+
+def round_bf16(a):
+    """float32 -> nearest-even bfloat16 -> float32 (numpy, no torch dependency)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+    return r.view(np.float32).reshape(np.shape(a))
+
+
+@contextlib.contextmanager
+def precision(mode):
+    global _Q, _QW
+    assert mode in ("fp32", "bf16")
+    old = (_Q, _QW)
+    if mode == "bf16":
+        _Q = _QW = round_bf16
+    try:
+        yield
+    finally:
+        _Q, _QW = old
+
+
 # --------------------------------------------------------------------------- shape algebra
 def generator_edges(n):
     """Spatial edge after every layer of unet_generator (generator.py:48-115 comments)."""
@@ -155,27 +187,28 @@ def generator_forward(P, x, is3d=True, training=False, drop=None, in_pad=0):
     S, Pd = (lambda s: _stride(is3d, s)), (lambda p: _pad(is3d, p))
     lr = ops.leaky_relu
     sv = {"x": x, "in_pad": in_pad, "is3d": is3d}
-    a0 = lr(ops.conv_fwd(x, P["c0"], S(1), Pd(in_pad)))
-    s0 = lr(ops.conv_fwd(a0, P["d1a"], S(1), Pd(0)))                 # skip0 == before_down
-    d1 = lr(ops.conv_fwd(s0, P["d1b"], S(2), Pd(0)))
-    s1 = lr(ops.conv_fwd(d1, P["d2a"], S(1), Pd(0)))                 # skip1
-    d2 = lr(ops.conv_fwd(s1, P["d2b"], S(2), Pd(0)))
-    b2 = lr(ops.conv_fwd(d2, P["u2a"], S(1), Pd(0)))
-    c2 = ops.convT_fwd(b2, P["u2b"], S(2), Pd(1))
+    Q, W = _Q, (lambda k: _QW(P[k]))                                # storage points of the bf16 mode (identity in fp32)
+    a0 = Q(lr(ops.conv_fwd(x, W("c0"), S(1), Pd(in_pad))))
+    s0 = Q(lr(ops.conv_fwd(a0, W("d1a"), S(1), Pd(0))))              # skip0 == before_down
+    d1 = Q(lr(ops.conv_fwd(s0, W("d1b"), S(2), Pd(0))))
+    s1 = Q(lr(ops.conv_fwd(d1, W("d2a"), S(1), Pd(0))))              # skip1
+    d2 = Q(lr(ops.conv_fwd(s1, W("d2b"), S(2), Pd(0))))
+    b2 = Q(lr(ops.conv_fwd(d2, W("u2a"), S(1), Pd(0))))
+    c2 = ops.convT_fwd(b2, W("u2b"), S(2), Pd(1))
     k2 = _keep(c2.shape, training, drop, 0)
-    u2 = lr(c2 * k2)
+    u2 = Q(lr(c2 * k2))
     edge = lambda t: t.shape[3]
     lo1, hi1 = skip_crop(edge(s1), edge(u2))
     cat1 = np.concatenate([u2, _crop(s1, lo1, hi1, is3d)], axis=-1)  # generator.py:85 order
-    m = lr(ops.conv_fwd(cat1, P["mid"], S(1), Pd(0)))
-    b1 = lr(ops.conv_fwd(m, P["u1a"], S(1), Pd(0)))
-    c1 = ops.convT_fwd(b1, P["u1b"], S(2), Pd(1))
+    m = Q(lr(ops.conv_fwd(cat1, W("mid"), S(1), Pd(0))))
+    b1 = Q(lr(ops.conv_fwd(m, W("u1a"), S(1), Pd(0))))
+    c1 = ops.convT_fwd(b1, W("u1b"), S(2), Pd(1))
     k1 = _keep(c1.shape, training, drop, 1)
-    u1 = lr(c1 * k1)
+    u1 = Q(lr(c1 * k1))
     lo0, hi0 = skip_crop(edge(s0), edge(u1))
     cat0 = np.concatenate([u1, _crop(s0, lo0, hi0, is3d)], axis=-1)
-    f1 = lr(ops.conv_fwd(cat0, P["f1"], S(1), Pd(0)))
-    y = ops.conv_fwd(f1, P["f2"], S(1), Pd(0))
+    f1 = Q(lr(ops.conv_fwd(cat0, W("f1"), S(1), Pd(0))))
+    y = Q(ops.conv_fwd(f1, W("f2"), S(1), Pd(0)))
     sv.update(a0=a0, s0=s0, d1=d1, s1=s1, d2=d2, b2=b2, u2=u2, k2=k2, cat1=cat1, m=m, b1=b1,
               u1=u1, k1=k1, cat0=cat0, f1=f1, lo1=lo1, lo0=lo0)
     return y, sv
@@ -217,38 +250,39 @@ def generator_backward(P, sv, dy, need_dx=False):
     c1n = P["u1b"].shape[3]            # channels of u1 (first half of cat0)
     c2n = P["u2b"].shape[3]
 
+    Q, W = _Q, (lambda k: _QW(P[k]))
     G["f2"] = ops.conv_bwd_weight(sv["f1"], dy, k3, S(1), Pd(0))
-    g_f1 = gate(ops.conv_bwd_data(dy, P["f2"], sv["f1"].shape, S(1), Pd(0)), "f1")
+    g_f1 = Q(gate(ops.conv_bwd_data(dy, W("f2"), sv["f1"].shape, S(1), Pd(0)), "f1"))
     G["f1"] = ops.conv_bwd_weight(sv["cat0"], g_f1, k3, S(1), Pd(0))
-    g_cat0 = ops.conv_bwd_data(g_f1, P["f1"], sv["cat0"].shape, S(1), Pd(0))
-    g_c1 = gate(g_cat0[..., :c1n], "u1") * sv["k1"]
-    t_skip0 = g_cat0[..., c1n:]
+    g_cat0 = ops.conv_bwd_data(g_f1, W("f1"), sv["cat0"].shape, S(1), Pd(0))
+    g_c1 = Q(gate(g_cat0[..., :c1n], "u1") * sv["k1"])
+    t_skip0 = Q(g_cat0[..., c1n:])
     G["u1b"] = ops.convT_bwd_weight(sv["b1"], g_c1, k4, S(2), Pd(1))
-    g_b1 = gate(ops.convT_bwd_data(g_c1, P["u1b"], sv["b1"].shape, S(2), Pd(1)), "b1")
+    g_b1 = Q(gate(ops.convT_bwd_data(g_c1, W("u1b"), sv["b1"].shape, S(2), Pd(1)), "b1"))
     G["u1a"] = ops.conv_bwd_weight(sv["m"], g_b1, k3, S(1), Pd(0))
-    g_m = gate(ops.conv_bwd_data(g_b1, P["u1a"], sv["m"].shape, S(1), Pd(0)), "m")
+    g_m = Q(gate(ops.conv_bwd_data(g_b1, W("u1a"), sv["m"].shape, S(1), Pd(0)), "m"))
     G["mid"] = ops.conv_bwd_weight(sv["cat1"], g_m, k3, S(1), Pd(0))
-    g_cat1 = ops.conv_bwd_data(g_m, P["mid"], sv["cat1"].shape, S(1), Pd(0))
-    g_c2 = gate(g_cat1[..., :c2n], "u2") * sv["k2"]
-    t_skip1 = g_cat1[..., c2n:]
+    g_cat1 = ops.conv_bwd_data(g_m, W("mid"), sv["cat1"].shape, S(1), Pd(0))
+    g_c2 = Q(gate(g_cat1[..., :c2n], "u2") * sv["k2"])
+    t_skip1 = Q(g_cat1[..., c2n:])
     G["u2b"] = ops.convT_bwd_weight(sv["b2"], g_c2, k4, S(2), Pd(1))
-    g_b2 = gate(ops.convT_bwd_data(g_c2, P["u2b"], sv["b2"].shape, S(2), Pd(1)), "b2")
+    g_b2 = Q(gate(ops.convT_bwd_data(g_c2, W("u2b"), sv["b2"].shape, S(2), Pd(1)), "b2"))
     G["u2a"] = ops.conv_bwd_weight(sv["d2"], g_b2, k3, S(1), Pd(0))
-    g_d2 = gate(ops.conv_bwd_data(g_b2, P["u2a"], sv["d2"].shape, S(1), Pd(0)), "d2")
+    g_d2 = Q(gate(ops.conv_bwd_data(g_b2, W("u2a"), sv["d2"].shape, S(1), Pd(0)), "d2"))
     G["d2b"] = ops.conv_bwd_weight(sv["s1"], g_d2, k4, S(2), Pd(0))
-    g_s1 = ops.conv_bwd_data(g_d2, P["d2b"], sv["s1"].shape, S(2), Pd(0))
-    g_s1 = gate(g_s1 + _embed(t_skip1, sv["s1"].shape, sv["lo1"], is3d), "s1")
+    g_s1 = ops.conv_bwd_data(g_d2, W("d2b"), sv["s1"].shape, S(2), Pd(0))
+    g_s1 = Q(gate(g_s1 + _embed(t_skip1, sv["s1"].shape, sv["lo1"], is3d), "s1"))
     G["d2a"] = ops.conv_bwd_weight(sv["d1"], g_s1, k3, S(1), Pd(0))
-    g_d1 = gate(ops.conv_bwd_data(g_s1, P["d2a"], sv["d1"].shape, S(1), Pd(0)), "d1")
+    g_d1 = Q(gate(ops.conv_bwd_data(g_s1, W("d2a"), sv["d1"].shape, S(1), Pd(0)), "d1"))
     G["d1b"] = ops.conv_bwd_weight(sv["s0"], g_d1, k4, S(2), Pd(0))
-    g_s0 = ops.conv_bwd_data(g_d1, P["d1b"], sv["s0"].shape, S(2), Pd(0))
-    g_s0 = gate(g_s0 + _embed(t_skip0, sv["s0"].shape, sv["lo0"], is3d), "s0")
+    g_s0 = ops.conv_bwd_data(g_d1, W("d1b"), sv["s0"].shape, S(2), Pd(0))
+    g_s0 = Q(gate(g_s0 + _embed(t_skip0, sv["s0"].shape, sv["lo0"], is3d), "s0"))
     G["d1a"] = ops.conv_bwd_weight(sv["a0"], g_s0, k3, S(1), Pd(0))
-    g_a0 = gate(ops.conv_bwd_data(g_s0, P["d1a"], sv["a0"].shape, S(1), Pd(0)), "a0")
+    g_a0 = Q(gate(ops.conv_bwd_data(g_s0, W("d1a"), sv["a0"].shape, S(1), Pd(0)), "a0"))
     G["c0"] = ops.conv_bwd_weight(sv["x"], g_a0, k3, S(1), Pd(sv["in_pad"]))
     dx = None
     if need_dx:
-        dx = ops.conv_bwd_data(g_a0, P["c0"], sv["x"].shape, S(1), Pd(sv["in_pad"]))
+        dx = Q(ops.conv_bwd_data(g_a0, W("c0"), sv["x"].shape, S(1), Pd(sv["in_pad"])))
     # reorder like the parameter list
     return OrderedDict((k, G[k]) for k in P.keys()), dx
 
@@ -288,15 +322,16 @@ def discriminator_forward(P, x, is3d=True, prior=None):
     S, Pd = (lambda s: _stride(is3d, s)), (lambda p: _pad(is3d, p))
     lr = ops.leaky_relu
     sv = {"x": x, "is3d": is3d, "prior": prior}
+    Q, W = _Q, (lambda k: _QW(P[k]))
     if is3d:
-        e1 = lr(ops.conv_fwd(x, P["d1a"], S(1), Pd(0)))
-        e2 = lr(ops.conv_fwd(e1, P["d1b"], S(2), Pd(0)))
-        h = lr(ops.conv_fwd(e2, P["hack"], S(1), Pd(0)))
+        e1 = Q(lr(ops.conv_fwd(x, W("d1a"), S(1), Pd(0))))
+        e2 = Q(lr(ops.conv_fwd(e1, W("d1b"), S(2), Pd(0))))
+        h = Q(lr(ops.conv_fwd(e2, W("hack"), S(1), Pd(0))))
         sv.update(e1=e1, e2=e2)
     else:
-        h = lr(ops.conv_fwd(x, P["hack"], S(1), Pd(0)))             # F8: raw input
-    e3 = lr(ops.conv_fwd(h, P["d2a"], S(1), Pd(0)))
-    e4 = lr(ops.conv_fwd(e3, P["d2b"], S(2), Pd(0)))
+        h = Q(lr(ops.conv_fwd(x, W("hack"), S(1), Pd(0))))            # F8: raw input
+    e3 = Q(lr(ops.conv_fwd(h, W("d2a"), S(1), Pd(0))))
+    e4 = Q(lr(ops.conv_fwd(e3, W("d2b"), S(2), Pd(0))))
     cat = e4
     if prior is not None:
         feat, pacts = prior_forward(prior, x, is3d)                     # x2 = disc_prior(inp)
@@ -305,11 +340,11 @@ def discriminator_forward(P, x, is3d=True, prior=None):
         cat = np.concatenate([e4, feat], axis=-1)                       # Concatenate()([x, x2])
         sv.update(pacts=pacts)
     sv["cat"] = cat
-    e5 = lr(ops.conv_fwd(cat, P["d3a"], S(1), Pd(0)))
+    e5 = Q(lr(ops.conv_fwd(cat, W("d3a"), S(1), Pd(0))))
     # Downsample_3's trailing LeakyReLU followed by discriminator.py:74's second one
-    e6 = lr(lr(ops.conv_fwd(e5, P["d3b"], S(2), Pd(0))))
-    p1 = lr(ops.conv_fwd(e6, P["p1"], S(1), Pd(0)))
-    z = ops.conv_fwd(p1, P["p2"], S(1), Pd(0), bias=P["p2_bias"])
+    e6 = Q(lr(lr(ops.conv_fwd(e5, W("d3b"), S(2), Pd(0)))))
+    p1 = Q(lr(ops.conv_fwd(e6, W("p1"), S(1), Pd(0))))
+    z = Q(ops.conv_fwd(p1, W("p2"), S(1), Pd(0), bias=P["p2_bias"]))
     sv.update(h=h, e3=e3, e4=e4, e5=e5, e6=e6, p1=p1)
     return z, sv
 
@@ -327,39 +362,40 @@ def discriminator_backward(P, sv, dz, need_dx=False, need_dw=True):
         if need_dw:
             G[name] = ops.conv_bwd_weight(xin, g, k, S(s), Pd(0))
 
+    Q, W = _Q, (lambda k: _QW(P[k]))
     bw("p2", sv["p1"], dz, k1, 1)
     if need_dw:
         G["p2_bias"] = np.asarray(dz, np.float64).sum(axis=(0, 1, 2, 3))
-    g_p1 = gate(ops.conv_bwd_data(dz, P["p2"], sv["p1"].shape, S(1), Pd(0)), "p1")
+    g_p1 = Q(gate(ops.conv_bwd_data(dz, W("p2"), sv["p1"].shape, S(1), Pd(0)), "p1"))
     bw("p1", sv["e6"], g_p1, k1, 1)
-    g_e6 = gate(ops.conv_bwd_data(g_p1, P["p1"], sv["e6"].shape, S(1), Pd(0)), "e6", DOUBLE_LEAKY)  # adjoint of lrelu(lrelu(.)) gated on the final output
+    g_e6 = Q(gate(ops.conv_bwd_data(g_p1, W("p1"), sv["e6"].shape, S(1), Pd(0)), "e6", DOUBLE_LEAKY))  # adjoint of lrelu(lrelu(.))
     bw("d3b", sv["e5"], g_e6, k4, 2)
-    g_e5 = gate(ops.conv_bwd_data(g_e6, P["d3b"], sv["e5"].shape, S(2), Pd(0)), "e5")
+    g_e5 = Q(gate(ops.conv_bwd_data(g_e6, W("d3b"), sv["e5"].shape, S(2), Pd(0)), "e5"))
     bw("d3a", sv["cat"], g_e5, k3, 1)
-    g_cat = ops.conv_bwd_data(g_e5, P["d3a"], sv["cat"].shape, S(1), Pd(0))
+    g_cat = ops.conv_bwd_data(g_e5, W("d3a"), sv["cat"].shape, S(1), Pd(0))
     c4 = sv["e4"].shape[-1]
-    g_e4 = gate(g_cat[..., :c4], "e4")
+    g_e4 = Q(gate(g_cat[..., :c4], "e4"))
     dx_prior = None
     if sv.get("prior") is not None and need_dx:
         dx_prior = prior_backward_data(sv["prior"], sv["pacts"], sv["x"].shape,
                                        np.ascontiguousarray(g_cat[..., c4:]), is3d)
     bw("d2b", sv["e3"], g_e4, k4, 2)
-    g_e3 = gate(ops.conv_bwd_data(g_e4, P["d2b"], sv["e3"].shape, S(2), Pd(0)), "e3")
+    g_e3 = Q(gate(ops.conv_bwd_data(g_e4, W("d2b"), sv["e3"].shape, S(2), Pd(0)), "e3"))
     bw("d2a", sv["h"], g_e3, k3, 1)
-    g_h = gate(ops.conv_bwd_data(g_e3, P["d2a"], sv["h"].shape, S(1), Pd(0)), "h")
+    g_h = Q(gate(ops.conv_bwd_data(g_e3, W("d2a"), sv["h"].shape, S(1), Pd(0)), "h"))
     dx = None
     if is3d:
         bw("hack", sv["e2"], g_h, k3, 1)
-        g_e2 = gate(ops.conv_bwd_data(g_h, P["hack"], sv["e2"].shape, S(1), Pd(0)), "e2")
+        g_e2 = Q(gate(ops.conv_bwd_data(g_h, W("hack"), sv["e2"].shape, S(1), Pd(0)), "e2"))
         bw("d1b", sv["e1"], g_e2, k4, 2)
-        g_e1 = gate(ops.conv_bwd_data(g_e2, P["d1b"], sv["e1"].shape, S(2), Pd(0)), "e1")
+        g_e1 = Q(gate(ops.conv_bwd_data(g_e2, W("d1b"), sv["e1"].shape, S(2), Pd(0)), "e1"))
         bw("d1a", sv["x"], g_e1, k3, 1)
         if need_dx:
-            dx = ops.conv_bwd_data(g_e1, P["d1a"], sv["x"].shape, S(1), Pd(0))
+            dx = Q(ops.conv_bwd_data(g_e1, W("d1a"), sv["x"].shape, S(1), Pd(0)))
     else:
         bw("hack", sv["x"], g_h, k3, 1)
         if need_dx:
-            dx = ops.conv_bwd_data(g_h, P["hack"], sv["x"].shape, S(1), Pd(0))
+            dx = Q(ops.conv_bwd_data(g_h, W("hack"), sv["x"].shape, S(1), Pd(0)))
     if dx is not None and dx_prior is not None:
         dx = (dx + dx_prior).astype(np.float32)
     grads = OrderedDict((k, G[k]) for k in P.keys()) if need_dw else None
@@ -410,6 +446,7 @@ def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, see
     gates: optional callable(saved) -> {call: {saved key: bool array}} evaluated after the forward passes;
     the backward passes then take every listed LeakyReLU branch from it (see _gate_on).
     Returns (losses7: float64[7] in the reference's return order, grads dict, aux)."""
+    real_x, real_y = _Q(real_x), _Q(real_y)                          # bf16 mode: the inputs are cast once per step
     n = real_x.shape[3]
     out = generator_out(n)
     b = (n - out) // 2                                               # cgan.py:65
@@ -451,7 +488,7 @@ def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, see
     disc_y, dzr_y, dzf_y = discriminator_loss(z_ry, z_fy, gamma)
     losses = np.array([total_gen_g, total_gen_f, disc_y, disc_x, gen_g, gen_f, total_cycle], np.float64)
 
-    f32 = lambda a: np.asarray(a, np.float32)
+    f32 = lambda a: _Q(np.asarray(a, np.float32))                    # loss gradients are stored like activations
     # ---- generator sweep: d S / d theta_G, d S / d theta_F
     gG3, _ = generator_backward(Pg, sv_g3, f32(dsame_y))
     gF3, _ = generator_backward(Pf, sv_f3, f32(dsame_x))
@@ -461,8 +498,8 @@ def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, see
     # adversarial: d gen_g / d fake_y through D_y (weights of D not differentiated here)
     _, d_fy_adv = discriminator_backward(Pdy, sv_dyf, f32(dz_gen_g), need_dx=True, need_dw=False)
     _, d_fx_adv = discriminator_backward(Pdx, sv_dxf, f32(dz_gen_f), need_dx=True, need_dw=False)
-    d_fake_y = (d_fy_pad + d_fy_adv).astype(np.float32)   # in_pad handled inside: dx is un-padded
-    d_fake_x = (d_fx_pad + d_fx_adv).astype(np.float32)
+    d_fake_y = _Q((d_fy_pad + d_fy_adv).astype(np.float32))   # in_pad handled inside: dx is un-padded
+    d_fake_x = _Q((d_fx_pad + d_fx_adv).astype(np.float32))
     gG1, _ = generator_backward(Pg, sv_g1, d_fake_y)
     gF1, _ = generator_backward(Pf, sv_f1, d_fake_x)
     grad_g = OrderedDict((k, gG1[k] + gG2[k] + gG3[k]) for k in Pg)

@@ -215,3 +215,80 @@ def test_pack_weights_and_elementwise_bf16(H, oracle_lib):
     u, v = devb(a), devb(b)
     H.run([H.copy_view_launch("t", u, v, add=True)])
     assert np.array_equal(v.float().cpu().numpy(), rb(a + b))
+
+
+def _inputs(shape, seed):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, 256, shape[:-1], dtype=np.uint8)
+    x = (u.astype(np.float32) / np.float32(127.5) - np.float32(1.0))[..., None]
+    return ((x - x.mean()) / x.std()).astype(np.float32)
+
+
+def _l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def test_generator_inference_bf16(oracle_lib):
+    """generator_g in bf16 (inference: dropout off) vs the oracle rounding at the same storage points.  Every layer
+    rounds its output to bf16 (2^-9 relative), ties between the fp32 chain and the oracle's double sums can round the
+    other way, and 12 layers compound: the bar is 2e-2 of the output range, 5e-3 in the L2 norm."""
+    from oracle import graph
+    from transfer_em_amd.models.generator import unet_generator
+    from util import scaled_params
+    model, out = unet_generator(74)
+    P = scaled_params(graph.generator_param_shapes(True), 3)
+    model.params.load_dict(P)
+    x = _inputs((1, 74, 74, 74, 1), 99)
+    y = model(torch.from_numpy(x).to(torch.bfloat16)).float().cpu().numpy()
+    with graph.precision("bf16"):
+        ref, _ = graph.generator_forward(P, graph.round_bf16(x), True, training=False)
+    assert y.shape == (1, 40, 40, 40, 1)
+    print("bf16 generator: max-rel", rel_err(y, ref), "l2", _l2(y, ref))
+    assert rel_err(y, ref) < 2e-2 and _l2(y, ref) < 5e-3
+    y32 = model(torch.from_numpy(x)).cpu().numpy()                         # and it IS a different arithmetic than fp32
+    assert 1e-4 < _l2(y, y32) < 3e-2
+
+
+def test_train_step_bf16_matches_oracle(tmp_path, oracle_lib):
+    """EM2EM(precision='bf16').train_step at 74^3: losses, generator outputs, all four gradient sets (fp32 slabs) and
+    the Adam moments vs the oracle in its bf16 storage mode, with the LeakyReLU branches taken from the HIP forward
+    (util.hip_gates).  Gradients are compared in the L2 norm per kernel: individual bf16-rounded activations differ
+    by an ulp here and there, which moves single gradient entries by more than any fixed max-norm bar."""
+    from oracle import graph
+    from transfer_em_amd.cgan import EM2EM
+    from test_gpu_step import _load, _state
+    from util import hip_gates, gate_flips
+    n, shape = 74, (1, 74, 74, 74, 1)
+    rx, ry = _inputs(shape, 1234), _inputs(shape, 5678)
+    st = _state(graph, True, True)
+    model = EM2EM(n, "bf16", seed=42, checkpoint_root=str(tmp_path), precision="bf16")
+    _load(model, st)
+    got = model.train_step(torch.from_numpy(rx), torch.from_numpy(ry)).cpu().numpy()
+    cs = model._steps[1]
+    grads_hip = {k: net.params.to_dict("grad") for k, net in zip(("g", "f", "dx", "dy"), model._nets)}
+    with graph.precision("bf16"):
+        losses, grads, aux = graph.train_step(st, rx, ry, True, 2.0, 42, gates=hip_gates(cs, True))
+    print("bf16 step losses", got, losses, "flips", gate_flips(cs, aux["saved"], True))
+    assert rel_err(got, losses) < 5e-3, (got, losses)
+    b = model.buffer
+    crop = lambda t: t[:, b:-b, b:-b, b:-b, :]
+    for key, plan in (("fake_y", "g1"), ("cyc_x", "f2"), ("fake_x", "f1"), ("cyc_y", "g2"), ("same_x", "f3"), ("same_y", "g3")):
+        ref = crop(aux[key]) if key.startswith("cyc") else aux[key]
+        e = _l2(cs.fwd[plan].y.float().cpu().numpy(), ref)
+        assert e < 1e-2, (key, e)
+    worst = 0.0
+    for net in ("g", "f", "dx", "dy"):
+        for name, ref in grads[net].items():
+            if name.endswith("_bias"):
+                continue
+            e = _l2(grads_hip[net][name], ref)
+            worst = max(worst, e)
+            assert e < 4e-2, (net, name, e)
+    print("bf16 step: worst kernel-gradient L2 error", worst)
+    for net, obj in zip(("g", "f", "dx", "dy"), model._nets):
+        m = obj.params.to_dict("m")
+        for name, ref in st["m"][net].items():
+            if not name.endswith("_bias"):
+                assert _l2(m[name], ref) < 4e-2, (net, name)
+    assert model.generator_g.params.theta.dtype == torch.float32            # fp32 master weights

@@ -57,7 +57,7 @@ def gate_flips(cs, saved, is3d=True):
             if call[0] in "gf":
                 lo, hi = fwd.regions[layer]
                 ref = ref[:, lo:hi, lo:hi, lo:hi, :] if is3d else ref[:, :, lo:hi, lo:hi, :]
-            got = fwd.act[layer].cpu().numpy()
+            got = fwd.act[layer].float().cpu().numpy()
             n += int(np.count_nonzero((got > 0) != (ref > 0)))
     return n
 
@@ -81,7 +81,7 @@ def hip_gates(cs, is3d=True):
                 if key not in sv or layer not in fwd.act:
                     continue
                 pos = np.asarray(sv[key]) > 0
-                got = fwd.act[layer].cpu().numpy() > 0
+                got = fwd.act[layer].float().cpu().numpy() > 0
                 if gen:
                     lo, hi = fwd.regions[layer]
                     if is3d:

@@ -54,20 +54,29 @@ class _CompiledStep:
         self.real_y = torch.zeros(shp, dtype=torch.float32, device=dev)
         self.losses = torch.zeros(8, dtype=torch.float64, device=dev)
         G, F, DX, DY = m.generator_g, m.generator_f, m.discriminator_x, m.discriminator_y
+        bf = m.dtype == torch.bfloat16
+        if bf:
+            # bf16 mixed precision (BASELINE config 5): the inputs are cast once per step; every activation, loss
+            # gradient and the per-step kernel copies are bf16; slabs, gradients, Adam and the master weights fp32
+            self.in_x, self.in_y = (torch.zeros(shp, dtype=torch.bfloat16, device=dev) for _ in range(2))
+            casts = [H.cast_bf16_launch("cast.x", self.real_x, self.in_x), H.cast_bf16_launch("cast.y", self.real_y, self.in_y)]
+        else:
+            self.in_x, self.in_y, casts = self.real_x, self.real_y, []
+        real_x, real_y = self.in_x, self.in_y
         drop = lambda call: (m.seed, call, m.step_dev)
         cr = lambda t, c: H.crop(t, c, c, is3d)
         kw = dict(direct=direct)
         kwb = dict(direct=direct, refresh_wt=False)       # theta_t is refreshed once per network below
 
         # ---- forward (cgan.py:152-189)
-        f_g1 = GenForward(G, self.real_x, training=True, drop=drop(CALL_G_FAKE_Y), **kw)
+        f_g1 = GenForward(G, real_x, training=True, drop=drop(CALL_G_FAKE_Y), **kw)
         # cycle path: only the window of `cycled` that survives the crop (cgan.py:163,172) is evaluated
         f_f2 = GenForward(F, f_g1.y, in_pad=b, training=True, drop=drop(CALL_F_CYC_X), out_crop=b, **kw)
-        f_f1 = GenForward(F, self.real_y, training=True, drop=drop(CALL_F_FAKE_X), **kw)
+        f_f1 = GenForward(F, real_y, training=True, drop=drop(CALL_F_FAKE_X), **kw)
         f_g2 = GenForward(G, f_f1.y, in_pad=b, training=True, drop=drop(CALL_G_CYC_Y), out_crop=b, **kw)
-        f_f3 = GenForward(F, self.real_x, training=True, drop=drop(CALL_F_SAME_X), **kw)
-        f_g3 = GenForward(G, self.real_y, training=True, drop=drop(CALL_G_SAME_Y), **kw)
-        x_c, y_c = cr(self.real_x, b), cr(self.real_y, b)
+        f_f3 = GenForward(F, real_x, training=True, drop=drop(CALL_F_SAME_X), **kw)
+        f_g3 = GenForward(G, real_y, training=True, drop=drop(CALL_G_SAME_Y), **kw)
+        x_c, y_c = cr(real_x, b), cr(real_y, b)
         d_xr = DiscForward(DX, x_c, **kw)
         d_yr = DiscForward(DY, y_c, **kw)
         d_xf = DiscForward(DX, f_f1.y, **kw)
@@ -87,9 +96,9 @@ class _CompiledStep:
         loss = [
             H.focal_logits_launch("loss.gen_g", d_yf.z, 1, gamma, Ls, _bits(L_TOTAL_G, L_GEN_G), 2.0, dz_gen_g, 2.0),
             H.focal_logits_launch("loss.gen_f", d_xf.z, 1, gamma, Ls, _bits(L_TOTAL_F, L_GEN_F), 2.0, dz_gen_f, 2.0),
-            H.focal_match_launch("loss.cyc_x", cr(self.real_x, 2 * b), f_f2.y, gamma, Ls,
+            H.focal_match_launch("loss.cyc_x", cr(real_x, 2 * b), f_f2.y, gamma, Ls,
                                  _bits(L_TOTAL_G, L_TOTAL_F, L_CYCLE), 4.0, dcyc_x, 4.0),
-            H.focal_match_launch("loss.cyc_y", cr(self.real_y, 2 * b), f_g2.y, gamma, Ls,
+            H.focal_match_launch("loss.cyc_y", cr(real_y, 2 * b), f_g2.y, gamma, Ls,
                                  _bits(L_TOTAL_G, L_TOTAL_F, L_CYCLE), 4.0, dcyc_y, 4.0),
             H.focal_match_launch("loss.id_y", y_c, f_g3.y, gamma, Ls, _bits(L_TOTAL_G), 2.0, dsame_y, 2.0),
             H.focal_match_launch("loss.id_x", x_c, f_f3.y, gamma, Ls, _bits(L_TOTAL_F), 2.0, dsame_x, 2.0),
@@ -127,8 +136,11 @@ class _CompiledStep:
             backward += p.launches
         red = {k: w.reduce_launches(k) for k, w in (("g", wg), ("f", wf), ("dx", wdx), ("dy", wdy))}
         reduce_ = red["g"] + red["f"] + red["dx"] + red["dy"]
-        flips = {k: net.params.flip_transpose_launch(k + ".flip_transpose") for k, net in (("g", G), ("f", F), ("dx", DX), ("dy", DY))}
-        self.compute = list(flips.values()) + forward + loss + backward + reduce_   # flat order (single stream, profiling)
+        # once per network and step: the kernel copies the input-gradient convolutions read (fp32: tap-reversed /
+        # transposed theta_t; bf16: the two bf16 copies every convolution reads)
+        flips = {k: (net.params.pack_bf16_launch(k + ".pack_bf16") if bf else net.params.flip_transpose_launch(k + ".flip_transpose"))
+                 for k, net in (("g", G), ("f", F), ("dx", DX), ("dy", DY))}
+        self.compute = casts + list(flips.values()) + forward + loss + backward + reduce_   # flat order (single stream, profiling)
         self._keep = (wg, wf, wdx, wdy, dz_gen_g, dz_gen_f, dz_rx, dz_fx, dz_ry, dz_fy, dcyc_x, dcyc_y, dsame_x, dsame_y)
 
         # ---- two-stream schedule.  The discriminators' layers are small (20^3 .. 8^3 voxels deep in the
@@ -139,7 +151,7 @@ class _CompiledStep:
         L_ = lambda *plans: [l for pl in plans for l in pl.launches]
         main, side, third = [], [], []
         # side: discriminators (one stream for both: a stream per discriminator measured no different)
-        side += [("wait", "inputs"), flips["dx"], flips["dy"]] + L_(d_xr, d_yr)
+        side += [("wait", "inputs"), flips["dx"], flips["dy"], ("wait", "cast")] + L_(d_xr, d_yr)
         side += [("wait", "fake_y")] + L_(d_yf) + [("wait", "fake_x")] + L_(d_xf)
         side += [loss[0], loss[1]] + loss[6:10] + L_(a_dy, a_dx) + [("record", "adv")]
         side += L_(w_dxr, w_dxf, w_dyr, w_dyf) + red["dx"] + red["dy"] + [("record", "side_done")]
@@ -148,8 +160,8 @@ class _CompiledStep:
         # generators' kernel-gradient launches to two more streams (16.4 vs 15.75 ms/step -- the extra
         # LDS-bound kernels only steal CUs from the dependent chains) and HIP stream priorities for the
         # chains (17.9 ms/step).
-        main += [flips["g"]] + L_(f_g1) + [("record", "fake_y")] + L_(f_g3) + [("wait", "fake_x")] + L_(f_g2)
-        third += [("wait", "inputs"), flips["f"]] + L_(f_f1) + [("record", "fake_x")] + L_(f_f3) + [("wait", "fake_y")] + L_(f_f2)
+        main += casts + [("record", "cast")] + [flips["g"]] + L_(f_g1) + [("record", "fake_y")] + L_(f_g3) + [("wait", "fake_x")] + L_(f_g2)
+        third += [("wait", "inputs"), flips["f"], ("wait", "cast")] + L_(f_f1) + [("record", "fake_x")] + L_(f_f3) + [("wait", "fake_y")] + L_(f_f2)
         main += [loss[3], loss[4]] + L_(b_g3, b_g2) + [("record", "d_fake_x")]
         third += [loss[2], loss[5]] + L_(b_f3, b_f2) + [("record", "d_fake_y")]
         main += [("wait", "adv"), ("wait", "d_fake_y"), add_y] + L_(b_g1) + red["g"]
@@ -211,10 +223,17 @@ class EM2EM(object):
 
     def __init__(self, dimsize, exp_name, is3d=True, norm_type="instancenorm", ckpt_restore=None, wf=8,
                  focal_gamma=2, disc_prior=None, device=None, seed=42, weight_seeds=(0, 1, 2, 3), nslab=32,
-                 process_group=None, checkpoint_root="./checkpoints", two_streams=True, use_graph=None):
+                 process_group=None, checkpoint_root="./checkpoints", two_streams=True, use_graph=None,
+                 precision="fp32"):
         if dimsize < 74:
             raise RuntimeError("minimum dimension allowed is 74")            # cgan.py:52-53
         H.require_gpu()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' (the reference's arithmetic, cgan.py:13-14) or 'bf16' (mixed precision: "
+                             "bf16 activations and kernel copies, fp32 accumulation / master weights / Adam)")
+        if precision == "bf16" and (not is3d or disc_prior is not None):
+            raise RuntimeError("bf16 mixed precision is built for the 3-D networks without a prior")
+        self.precision, self.dtype = precision, (torch.bfloat16 if precision == "bf16" else torch.float32)
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
         self.dimsize, self.exp_name, self.is3d = dimsize, exp_name, is3d
         self.focal_gamma, self.nslab = focal_gamma, nslab

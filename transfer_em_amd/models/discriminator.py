@@ -73,6 +73,12 @@ class DiscForward:
     def __init__(self, net, x, direct=False):
         P, is3d = net.params, net.is3d
         self.net, self.x = net, x
+        self.dtype = x.dtype
+        bf = self.bf16 = x.dtype == torch.bfloat16           # bf16 mixed precision: see models/generator.GenForward
+        if bf:
+            if not is3d or net.prior is not None:
+                raise RuntimeError("bf16 mixed precision is built for the 3-D networks without a prior")
+            P.enable_bf16()
         N = x.shape[0]
         e = self.edges = discriminator_edges(x.shape[3], is3d)
         self.order = _ORDER3 if is3d else _ORDER2
@@ -84,8 +90,7 @@ class DiscForward:
             n = e[name]
             if n < 1:
                 raise RuntimeError(f"input edge {x.shape[3]} is too small for the discriminator")
-            A[name] = torch.empty((N, n if is3d else 1, n, n, P.shapes[name][-1]), dtype=torch.float32,
-                                  device=x.device)
+            A[name] = torch.empty((N, n if is3d else 1, n, n, P.shapes[name][-1]), dtype=x.dtype, device=x.device)
             k, s = _GEOM[name]
             in1 = None
             if name == "d3a" and net.prior is not None:
@@ -97,7 +102,8 @@ class DiscForward:
                     raise RuntimeError(f"disc_prior output {tuple(in1.shape)} does not match Downsample_2's "
                                        f"output {tuple(prev.shape)}")
                 L.extend(self.prior_fwd.launches)
-            L.append(H.conv_launch("d." + name, prev, P.w(name), A[name], k, s, 0, is3d=is3d if k > 1 else True,
+            L.append(H.conv_launch("d." + name, prev, P.wht(name) if bf else P.w(name), A[name], k, s, 0,
+                                   is3d=is3d if k > 1 else True,
                                    in1=in1, slope=_SLOPE.get(name, H.LEAKY),
                                    bias=P.w("p2_bias") if name == "p2" else None, direct=direct))
             prev = A[name]
@@ -120,8 +126,9 @@ class DiscBackward:
         G = self.grads = {k: torch.empty_like(A[k]) for k in order[:-1]}
         self.dx = torch.empty_like(fwd.x) if need_dx else None
         L = self.launches = []
+        bf = fwd.bf16
         if refresh_wt:                       # see GenBackward: theta_t for the wide layers' input-gradients
-            L.append(P.flip_transpose_launch("d.flip_transpose"))
+            L.append(P.pack_bf16_launch("d.pack_bf16") if bf else P.flip_transpose_launch("d.flip_transpose"))
         g_out = dz
         pf = fwd.prior_fwd
         g_feat = torch.empty_like(pf.y) if pf is not None else None
@@ -145,13 +152,15 @@ class DiscBackward:
                 # with a prior the gradient of the concat splits: channels 0..31 to the trunk (gated by
                 # Downsample_2's LeakyReLU), the rest, ungated, to the prior's output
                 shp = P.shapes[name]
-                use_t = shp[4] >= 16 and shp[3] >= 8
-                L.append(H.conv_launch("d.bd." + name, g_out, P.w_t(name) if use_t else P.w(name), dst, k, 1, k - 1,
+                use_t = (not bf) and shp[4] >= 16 and shp[3] >= 8
+                L.append(H.conv_launch("d.bd." + name, g_out, P.wh(name) if bf else (P.w_t(name) if use_t else P.w(name)),
+                                       dst, k, 1, k - 1,
                                        is3d=i3, out1=g_feat if with_prior else None,
                                        layout=H.TEM_W_TAP_CI_CO if use_t else H.TEM_W_FLIP_CO_CI,
                                        gate=gate, gate_slope=gslope, direct=direct))
             else:
-                L.append(H.conv_launch("d.bd." + name, g_out, P.w(name), dst, k, s, 0, is3d=i3, transposed=True,
+                L.append(H.conv_launch("d.bd." + name, g_out, P.wh(name) if bf else P.w(name), dst, k, s, 0, is3d=i3,
+                                       transposed=True,
                                        gate=gate, gate_slope=gslope, direct=direct))
             g_out = dst
         self.prior_bwd = None

@@ -132,9 +132,19 @@ class GenForward:
     activation buffer then holds the region R[layer] of its logical tensor and the operators get the
     correspondingly shifted padding (conv: p' = p + lo_in - s*lo_out, transposed: p' = p + lo_out - s*lo_in)."""
 
-    def __init__(self, net, x, in_pad=0, training=False, drop=None, out_crop=0, direct=False):
+    def __init__(self, net, x, in_pad=0, training=False, drop=None, out_crop=0, direct=False, pack=False):
         P, is3d = net.params, net.is3d
         self.net, self.x, self.in_pad, self.training, self.drop = net, x, in_pad, training, drop
+        # bf16 mixed precision (BASELINE config 5): `x` and every activation are bf16, the kernels read the per-step
+        # bf16 copies of theta (Conv layers contract over the transposed copy theta_ht, ConvTranspose over theta_h)
+        self.dtype = dtype = x.dtype
+        bf = self.bf16 = dtype == torch.bfloat16
+        if bf:
+            if not is3d:
+                raise RuntimeError("bf16 mixed precision is built for the 3-D networks")
+            P.enable_bf16()
+        wf = P.wht if bf else P.w                 # forward Conv
+        wT = P.wh if bf else P.w                  # forward ConvTranspose
         N = x.shape[0]
         e = generator_edges(x.shape[3] + 2 * in_pad)
         self.edges = e
@@ -145,7 +155,7 @@ class GenForward:
 
         def alloc(layer):
             n = R[layer][1] - R[layer][0]
-            return torch.empty((N, n if is3d else 1, n, n, ch[layer]), dtype=torch.float32, device=x.device)
+            return torch.empty((N, n if is3d else 1, n, n, ch[layer]), dtype=dtype, device=x.device)
 
         A = self.act = {k: alloc(k) for k in ("c0", "d1a", "d1b", "d2a", "d2b", "u2a", "u2b", "mid", "u1a", "u1b",
                                               "f1", "f2")}
@@ -169,23 +179,25 @@ class GenForward:
         pc = lambda p, s, i, o: p + lo(i) - s * lo(o) if i else p - s * lo(o)      # conv-like pad ('' = full input x)
         pt = lambda p, s, i, o: p + lo(o) - s * lo(i)                               # transposed-conv pad
         L = self.launches = []
+        if bf and pack:                               # stand-alone plan (inference): refresh the bf16 kernel copies itself
+            L.append(P.pack_bf16_launch("g.pack_bf16"))
         cv = H.conv_launch
-        L.append(cv("g.c0", x, P.w("c0"), A["c0"], 3, 1, pc(in_pad, 1, "", "c0"), slope=H.LEAKY, **kw))
-        L.append(cv("g.d1a", A["c0"], P.w("d1a"), A["d1a"], 3, 1, pc(0, 1, "c0", "d1a"), slope=H.LEAKY, **kw))
-        L.append(cv("g.d1b", A["d1a"], P.w("d1b"), A["d1b"], 4, 2, pc(0, 2, "d1a", "d1b"), slope=H.LEAKY, **kw))
-        L.append(cv("g.d2a", A["d1b"], P.w("d2a"), A["d2a"], 3, 1, pc(0, 1, "d1b", "d2a"), slope=H.LEAKY, **kw))
-        L.append(cv("g.d2b", A["d2a"], P.w("d2b"), A["d2b"], 4, 2, pc(0, 2, "d2a", "d2b"), slope=H.LEAKY, **kw))
-        L.append(cv("g.u2a", A["d2b"], P.w("u2a"), A["u2a"], 3, 1, pc(0, 1, "d2b", "u2a"), slope=H.LEAKY, **kw))
-        L.append(cv("g.u2b", A["u2a"], P.w("u2b"), A["u2b"], 4, 2, pt(1, 2, "u2a", "u2b"), transposed=True,
+        L.append(cv("g.c0", x, wf("c0"), A["c0"], 3, 1, pc(in_pad, 1, "", "c0"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d1a", A["c0"], wf("d1a"), A["d1a"], 3, 1, pc(0, 1, "c0", "d1a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d1b", A["d1a"], wf("d1b"), A["d1b"], 4, 2, pc(0, 2, "d1a", "d1b"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d2a", A["d1b"], wf("d2a"), A["d2a"], 3, 1, pc(0, 1, "d1b", "d2a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d2b", A["d2a"], wf("d2b"), A["d2b"], 4, 2, pc(0, 2, "d2a", "d2b"), slope=H.LEAKY, **kw))
+        L.append(cv("g.u2a", A["d2b"], wf("u2a"), A["u2a"], 3, 1, pc(0, 1, "d2b", "u2a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.u2b", A["u2a"], wT("u2b"), A["u2b"], 4, 2, pt(1, 2, "u2a", "u2b"), transposed=True,
                     slope=H.LEAKY, dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]), keep_mask=km(0, 1), **kw))
-        L.append(cv("g.mid", A["u2b"], P.w("mid"), A["mid"], 3, 1, pc(0, 1, "u2b", "mid"), in1=self.skip1,
+        L.append(cv("g.mid", A["u2b"], wf("mid"), A["mid"], 3, 1, pc(0, 1, "u2b", "mid"), in1=self.skip1,
                     slope=H.LEAKY, **kw))
-        L.append(cv("g.u1a", A["mid"], P.w("u1a"), A["u1a"], 3, 1, pc(0, 1, "mid", "u1a"), slope=H.LEAKY, **kw))
-        L.append(cv("g.u1b", A["u1a"], P.w("u1b"), A["u1b"], 4, 2, pt(1, 2, "u1a", "u1b"), transposed=True,
+        L.append(cv("g.u1a", A["mid"], wf("u1a"), A["u1a"], 3, 1, pc(0, 1, "mid", "u1a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.u1b", A["u1a"], wT("u1b"), A["u1b"], 4, 2, pt(1, 2, "u1a", "u1b"), transposed=True,
                     slope=H.LEAKY, dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), keep_mask=km(1, 1), **kw))
-        L.append(cv("g.f1", A["u1b"], P.w("f1"), A["f1"], 3, 1, pc(0, 1, "u1b", "f1"), in1=self.skip0,
+        L.append(cv("g.f1", A["u1b"], wf("f1"), A["f1"], 3, 1, pc(0, 1, "u1b", "f1"), in1=self.skip0,
                     slope=H.LEAKY, **kw))
-        L.append(cv("g.f2", A["f1"], P.w("f2"), A["f2"], 3, 1, pc(0, 1, "f1", "f2"), slope=1.0, **kw))
+        L.append(cv("g.f2", A["f1"], wf("f2"), A["f2"], 3, 1, pc(0, 1, "f1", "f2"), slope=1.0, **kw))
         self.y = A["f2"]                                   # window [out_crop, out - out_crop) of the logical output
 
     def run(self, stream=None):
@@ -204,10 +216,11 @@ class GenBackward:
         self.fwd, self.dy = fwd, dy
         lo = lambda k: R[k][0]
 
+        bf, dtype = fwd.bf16, fwd.dtype
+
         def alloc(layer, c=None):
             n = R[layer][1] - R[layer][0]
-            return torch.empty((N, n if is3d else 1, n, n, ch[layer] if c is None else c), dtype=torch.float32,
-                               device=dev)
+            return torch.empty((N, n if is3d else 1, n, n, ch[layer] if c is None else c), dtype=dtype, device=dev)
 
         G = self.grads = {k: alloc(k) for k in ("c0", "d1a", "d1b", "d2a", "d2b", "u2a", "u2b", "mid", "u1a", "u1b",
                                                 "f1")}
@@ -232,11 +245,15 @@ class GenBackward:
         # the narrow ones keep reading theta in place through the TEM_W_FLIP_CO_CI layout.  refresh_wt: this plan
         # refreshes theta_t itself (stand-alone use); the train step does it once per network instead.
         if refresh_wt:
-            L.append(P.flip_transpose_launch("g.flip_transpose"))
+            L.append(P.pack_bf16_launch("g.pack_bf16") if bf else P.flip_transpose_launch("g.flip_transpose"))
 
         def wb(name):
+            if bf:                                   # bf16: un-transposed copy, taps reversed by the kernel
+                return dict(w=P.wh(name), layout=FL)
             s_ = P.shapes[name]
             return dict(w=P.w_t(name), layout=AS) if (s_[4] >= 16 and s_[3] >= 8) else dict(w=P.w(name), layout=FL)
+        wTb = P.wht if bf else P.w                   # input-gradient of a ConvTranspose (a k4 s2 conv over the gradient)
+        wSb = P.wh if bf else P.w                    # input-gradient of a stride-2 Conv (transposed-conv form)
 
         def cvb(lname, gin, name, gout, pad, **k2):
             wsel = wb(name)
@@ -249,7 +266,7 @@ class GenBackward:
                     gate=A["u1b"], dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]),
                     keep_mask=(fwd.keep[1], 2) if 1 in fwd.keep else None, **kw))
         L.append(bww("u1b", G["u1b"], A["u1a"], 4, 2, pc(1, 2, "u1b", "u1a")))
-        L.append(cv("g.bd.u1b", G["u1b"], P.w("u1b"), G["u1a"], 4, 2, pc(1, 2, "u1b", "u1a"), layout=AS,
+        L.append(cv("g.bd.u1b", G["u1b"], wTb("u1b"), G["u1a"], 4, 2, pc(1, 2, "u1b", "u1a"), layout=AS,
                     gate=A["u1a"], **kw))
         L.append(bww("u1a", A["mid"], G["u1a"], 3, 1, pc(0, 1, "mid", "u1a")))
         L.append(cvb("g.bd.u1a", G["u1a"], "u1a", G["mid"], pc(2, 1, "u1a", "mid"),
@@ -259,19 +276,19 @@ class GenBackward:
                     gate=A["u2b"], dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]),
                     keep_mask=(fwd.keep[0], 2) if 0 in fwd.keep else None, **kw))
         L.append(bww("u2b", G["u2b"], A["u2a"], 4, 2, pc(1, 2, "u2b", "u2a")))
-        L.append(cv("g.bd.u2b", G["u2b"], P.w("u2b"), G["u2a"], 4, 2, pc(1, 2, "u2b", "u2a"), layout=AS,
+        L.append(cv("g.bd.u2b", G["u2b"], wTb("u2b"), G["u2a"], 4, 2, pc(1, 2, "u2b", "u2a"), layout=AS,
                     gate=A["u2a"], **kw))
         L.append(bww("u2a", A["d2b"], G["u2a"], 3, 1, pc(0, 1, "d2b", "u2a")))
         L.append(cvb("g.bd.u2a", G["u2a"], "u2a", G["d2b"], pc(2, 1, "u2a", "d2b"),
                     gate=A["d2b"], **kw))
         L.append(bww("d2b", A["d2a"], G["d2b"], 4, 2, pc(0, 2, "d2a", "d2b")))
-        L.append(cv("g.bd.d2b", G["d2b"], P.w("d2b"), G["d2a"], 4, 2, pt(0, 2, "d2b", "d2a"), transposed=True,
+        L.append(cv("g.bd.d2b", G["d2b"], wSb("d2b"), G["d2a"], 4, 2, pt(0, 2, "d2b", "d2a"), transposed=True,
                     add=t_skip1, add_off=lo("u2b") + fwd.lo1 - lo("d2a"), gate=A["d2a"], **kw))
         L.append(bww("d2a", A["d1b"], G["d2a"], 3, 1, pc(0, 1, "d1b", "d2a")))
         L.append(cvb("g.bd.d2a", G["d2a"], "d2a", G["d1b"], pc(2, 1, "d2a", "d1b"),
                     gate=A["d1b"], **kw))
         L.append(bww("d1b", A["d1a"], G["d1b"], 4, 2, pc(0, 2, "d1a", "d1b")))
-        L.append(cv("g.bd.d1b", G["d1b"], P.w("d1b"), G["d1a"], 4, 2, pt(0, 2, "d1b", "d1a"), transposed=True,
+        L.append(cv("g.bd.d1b", G["d1b"], wSb("d1b"), G["d1a"], 4, 2, pt(0, 2, "d1b", "d1a"), transposed=True,
                     add=t_skip0, add_off=lo("u1b") + fwd.lo0 - lo("d1a"), gate=A["d1a"], **kw))
         L.append(bww("d1a", A["c0"], G["d1a"], 3, 1, pc(0, 1, "c0", "d1a")))
         L.append(cvb("g.bd.d1a", G["d1a"], "d1a", G["c0"], pc(2, 1, "d1a", "c0"),
@@ -304,22 +321,25 @@ class UNetGenerator:
     def forward_plan(self, x, **kw):
         return GenForward(self, x, **kw)
 
-    def plan(self, shape):
+    def plan(self, shape, dtype=torch.float32):
         """Cached inference launch plan for inputs of `shape` (N, D, H, W, 1): fill `plan.x`, call `plan.run()`;
-        the result `plan.y` is overwritten by the next run."""
-        key = tuple(int(v) for v in shape)
+        the result `plan.y` is overwritten by the next run.  dtype=torch.bfloat16: bf16 activations and kernel
+        copies (refreshed from theta by the plan's first launch)."""
+        key = tuple(int(v) for v in shape) + (dtype,)
         plan = self._plans.get(key)
         if plan is None:
-            buf = torch.empty(key, dtype=torch.float32, device=self.device)
-            plan = self._plans[key] = GenForward(self, buf)
+            buf = torch.empty(key[:-1], dtype=dtype, device=self.device)
+            plan = self._plans[key] = GenForward(self, buf, pack=True)
         return plan
 
     def __call__(self, x, training=False):
         """Inference forward (Keras __call__ without training=True: dropout off, cgan.py:289-293)."""
         if training:
             raise NotImplementedError("training-mode calls go through EM2EM.train_step")
-        x = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
-        plan = self.plan(x.shape)
+        x = torch.as_tensor(x, device=self.device)
+        dtype = torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32
+        x = x.to(dtype).contiguous()
+        plan = self.plan(x.shape, dtype)
         plan.x.copy_(x)
         return plan.run().clone()
 
