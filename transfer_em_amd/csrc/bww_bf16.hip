@@ -225,7 +225,9 @@ int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
     const int rows = (ty - 1) * S + K;
     const size_t xel = (((size_t)K * rows * p.colsA * PITCH) + 7) & ~(size_t)7, gel = (size_t)ty * p.OWp * GP + 16;
     const size_t bytes = ((xel + gel) * 2 + 15) & ~(size_t)15;
-    if ((size_t)K * rows * p.colsR * CPX > (size_t)PFX * 256 || (size_t)ty * p.OW * CPG > (size_t)PFG * 256 || bytes > 72 * 1024) break;
+    // two workgroups per CU (<= 72 KB each) where the patch allows; a single row band may take up to 120 KB
+    if ((size_t)K * rows * p.colsR * CPX > (size_t)PFX * 256 || (size_t)ty * p.OW * CPG > (size_t)PFG * 256 ||
+        bytes > (ty == 1 ? 120 : 72) * 1024) break;
     TY = ty; lds_bytes = bytes;
   }
   if (TY < 1) return TEM_EUNSUPPORTED;
@@ -251,7 +253,7 @@ int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   auto kern = bww_bf16_k<CI, CO, K, S, PFX, PFG, MTG>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }

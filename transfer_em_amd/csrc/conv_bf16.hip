@@ -462,7 +462,7 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   // k3 s1: forward layers and (flip) their input-gradients
   CB(1, 8, 3, 1, 12) CB(8, 1, 3, 1, 12) CB(1, 16, 3, 1, 12) CB(16, 1, 3, 1, 12)
   CB(8, 8, 3, 1, 12) CB(8, 16, 3, 1, 12) CB(16, 8, 3, 1, 12) CB(16, 16, 3, 1, 12)
-  CB(16, 32, 3, 1, 12) CB(32, 16, 3, 1, 12) CB(32, 32, 3, 1, 12)
+  CB(16, 32, 3, 1, 12) CB(32, 16, 3, 1, 12) CBG(32, 32, 3, 1, 12)     // 32 -> 32: 54 KB of fragments, read from L2 instead
   // k4 s2: strided forward layers and the input-gradients of the transposed convolutions
   CB(8, 8, 4, 2, 12) CB(16, 16, 4, 2, 12) CBG(32, 32, 4, 2, 12) CB(8, 16, 4, 2, 12) CBG(16, 32, 4, 2, 12)
   // 1x1 head of the discriminator and its gradients
