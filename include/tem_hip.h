@@ -102,6 +102,10 @@ typedef struct tem_epilogue {
  *                                                           stride-1 Keras Conv)       */
 #define TEM_W_TAP_CI_CO  0
 #define TEM_W_FLIP_CO_CI 1
+/* TEM_W_WINOGRAD: `w` is the layer's kernel in the Winograd F(2x2, 3x3) domain of the (y, x) axes as tem_winograd_weights wrote it
+ * (k 3, s 1, C_in and C_out in {8, 16} only; the call returns TEM_EUNSUPPORTED otherwise -- ask
+ * tem_conv_is_tiled first).  Same operator and epilogue; the result differs from the direct form by fp32 rounding. */
+#define TEM_W_WINOGRAD   2
 
 typedef struct tem_conv_args {
   tem_view in0, in1;          /* logical input = concat(in0, in1) on C; in1.ptr may be NULL */
@@ -282,6 +286,21 @@ typedef struct tem_wlayer {
  * Conv3DBackpropInputV2).  `layers_dev` is device memory. */
 int tem_flip_transpose(const float *theta, float *theta_t, const tem_wlayer *layers_dev, int32_t nlayers,
                        int64_t total, tem_stream_t stream);
+
+/* One kernel of tem_winograd_weights: the 27 taps of a [ci][co] block at theta + src_off (flip = 0: the operator's
+ * kernel is theta[tap][ci][co], a forward Conv layer; flip = 1: theta[26-tap][co][ci], its input-gradient) are
+ * transformed to U[kz] = G g[kz] G^T on the (y, x) axes (16 points per z tap) and written at u + dst_off in the fragment
+ * order of the Winograd kernel: (ci / 8) * 6144 floats per layer (ci, co <= 16 here: the operator's channel counts). */
+typedef struct tem_wino_layer {
+  int64_t src_off, dst_off;
+  int32_t ci, co, flip;
+} tem_wino_layer;
+
+/* Once per network and step, after the optimizer update (as tem_flip_transpose): the Winograd-domain copies of the
+ * listed kernels.  `layers_dev` is device memory.  (The reference leaves the choice of convolution algorithm to
+ * TF/cuDNN, which picks Winograd forms for 3x3 kernels the same way.) */
+int tem_winograd_weights(const float *theta, float *u, const tem_wino_layer *layers_dev, int32_t nlayers,
+                         tem_stream_t stream);
 
 /* g(view) = saved(view) > 0 ? g : slope * g, in place: LeakyReLU gradient gated on the saved output where no
  * convolution epilogue can carry it (gradient entering the frozen prior network, discriminator.py:62-66). */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtem_hip.so")
 
 TEM_OK, TEM_EINVAL, TEM_EUNSUPPORTED, TEM_ESHAPE = 0, -1, -2, -3
-TEM_W_TAP_CI_CO, TEM_W_FLIP_CO_CI = 0, 1
+TEM_W_TAP_CI_CO, TEM_W_FLIP_CO_CI, TEM_W_WINOGRAD = 0, 1, 2
 _ERR = {TEM_EINVAL: "TEM_EINVAL (malformed descriptor)",
         TEM_EUNSUPPORTED: "TEM_EUNSUPPORTED (geometry outside the compiled set)",
         TEM_ESHAPE: "TEM_ESHAPE (inconsistent tensor extents)"}
@@ -60,6 +60,10 @@ class tem_bww_args(C.Structure):
 class tem_reduce_item(C.Structure):
     _fields_ = [("slabs", C.c_void_p), ("stride", C.c_int64), ("nslab", C.c_int32), ("count", C.c_int32),
                 ("out", C.c_void_p)]
+
+
+class tem_wino_layer(C.Structure):
+    _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("ci", C.c_int32), ("co", C.c_int32), ("flip", C.c_int32)]
 
 
 _VP = C.POINTER(tem_view)
@@ -108,6 +112,7 @@ _SIGS = {
     "tem_add_view": [_VP, _VP, C.c_void_p],
     "tem_leaky_gate_view": [_VP, _VP, C.c_float, C.c_void_p],
     "tem_flip_transpose": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p],
+    "tem_winograd_weights": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
     "tem_instance_norm": [_VP, C.c_void_p, C.c_void_p, C.c_float, _VP, C.c_void_p, C.c_void_p, C.c_void_p],
     "tem_instance_norm_bwd": [_VP, _VP, C.c_void_p, C.c_void_p, C.c_void_p, _VP, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p],

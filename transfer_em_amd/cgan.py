@@ -65,7 +65,7 @@ class _CompiledStep:
         real_x, real_y = self.in_x, self.in_y
         drop = lambda call: (m.seed, call, m.step_dev)
         cr = lambda t, c: H.crop(t, c, c, is3d)
-        kw = dict(direct=direct)
+        kw = dict(direct=direct, refresh_u=False)          # theta_u is refreshed once per network (flips below)
         kwb = dict(direct=direct, refresh_wt=False)       # theta_t is refreshed once per network below
 
         # ---- forward (cgan.py:152-189)

@@ -1,0 +1,519 @@
+// wino.hip -- 3x3x3 stride-1 convolution (forward and input-gradient) of the narrow 3-D layers: Winograd
+// F(2x2, 3x3) on the (y, x) axes, direct sum over the three z taps, on the fp32 matrix cores.
+//
+//   Y[z] = sum_kz A^T [ sum_ci (G g[kz] G^T)(ci,co) (.) (B^T d[z + kz] B)(ci) ] A
+//
+// A 2x2 output tile of one plane needs a 4x4 input tile of three planes and 3 * 16 element-wise products per (ci, co)
+// instead of 27 * 4 multiply-adds: 2.25x fewer MFMA flops than the direct form, which is what bounds these layers
+// (C_in, C_out <= 16: the direct kernels run at 45 % of the matrix peak, far from HBM).  [The full 3-D form
+// F(2x2x2, 3x3x3) saves 3.375x but needs 64 accumulator tiles = all 256 AGPRs of a lane: one wave per SIMD, and with
+// nothing to switch to every LDS, VALU and store latency of the transforms is exposed -- measured slower than this.]
+//
+// GEMM view per Winograd point p (16) and z tap:  M_p[16 tiles][16 co] += V_p[16 tiles][4 ci] * U_p[4 ci][16 co]
+//   (v_mfma_f32_16x16x4_f32).  The A operand map of that instruction -- lane = (tile = lane & 15, k = lane >> 4) --
+//   is exactly "one (tile, channel) pair per lane": every lane reads the 4x4 raw voxels of ITS pair from the LDS image
+//   of the input plane, runs the input transform in its own registers (packed fp32 adds on two channels) and the
+//   transformed values ARE the A fragments: no shuffle, no LDS round trip between transform and MFMA.  The C/D map
+//   (col = co, row = tile) leaves a lane with all 16 points of (4 tiles, 1 co): the output transform is in-lane too.
+//   U (the transformed kernel, tem_winograd_weights) sits in LDS in fragment order (conflict-free ds_read_b64).
+//
+// Data movement: a workgroup of 8 waves (two per SIMD: one wave's transforms / stores run under the other's MFMAs)
+// owns a block of BY x BX tiles (four 16-tile MFMA row blocks, two waves each: one per output plane of the step) and
+// marches along z two output planes at a time over a ring of 4 input planes in LDS.  The 2 new planes of a step arrive
+// by LDS-DMA (buffer_load ... lds) over the 2 oldest planes once every wave is past them (two thirds into the step).
+// Zero padding (input-gradient: pad 2) = out-of-range buffer offsets, which arrive as zeros; concat inputs / split
+// outputs as in conv_lds.hip.
+//
+// Reference call sites: Conv3D(filters, 3) of models/utils.py:73,122 and generator.py:96 and their
+// Conv3DBackpropInput.  fp32 throughout; the result differs from the direct form by rounding only
+// (|err| ~ 1e-6 relative, tests/test_gpu_wino.py), inside north_star's 1e-3.
+#include "tem_common.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+namespace wino {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Ep32 {
+  float slope;
+  const float *gate; int32_t gN, gD, gH, gW; float gate_slope;
+  const uint8_t *keep_mask;      // dropout bits drawn by the forward pass (keep_mode 2) or NULL
+  int32_t doz, doy, dox, dD, dH, dW;
+};
+
+struct Dev {
+  const float *in0, *in1;
+  int32_t i0N, i0D, i0H, i0W, i1N, i1D, i1H, i1W;
+  int32_t C0;
+  int32_t N, D, H, W;
+  const float *u;
+  float *out0, *out1;
+  int32_t o0N, o0D, o0H, o0W, o1N, o1D, o1H, o1W;
+  int32_t CO0;
+  int32_t OD, OH, OW;
+  int32_t P;
+  int32_t BY, BX, nby, nbx, zsegs, zper, NTZ;
+  int32_t E, PLC, subb, slotb;   // even (= odd) x positions per plane row (BX + 1), 16-byte chunks and bytes per sub-image, bytes per ring slot
+  int32_t ndma;                  // LDS-DMA wave-instructions per sub-image (subb / 1024)
+  int32_t span0, span1;          // bytes one z-plane of in0 / in1 spans (buffer range of the plane's loads)
+  uint32_t magicBX, magicE;
+  int32_t dbg;
+  unsigned long long *stamps;    // diagnostic: per-phase cycle sums [block][wave][8] (null in normal runs)
+  Ep32 ep;
+};
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t x, uint32_t d, uint32_t magic) { return d == 1 ? x : __umulhi(x, magic); }
+
+// 1-D transforms of F(2,3)
+template <typename T> __device__ __forceinline__ void bt4(T &a, T &b, T &c, T &d) {   // B^T
+  const T v0 = a - c, v1 = b + c, v2 = c - b, v3 = b - d;
+  a = v0; b = v1; c = v2; d = v3;
+}
+template <typename T> __device__ __forceinline__ void at4(const T &a, const T &b, const T &c, const T &d, T &y0, T &y1) {   // A^T
+  const T s = b + c, t = b - c;
+  y0 = a + s; y1 = t - d;
+}
+
+// LDS image of one input plane (YR = 2 BY + 2 rows of 2 E voxels): one sub-image per 8 input channels (= per channel-pair
+// half h of the k loop; a concat input's two sources land in different sub-images), rows split into their even-x and
+// odd-x voxels:
+//   16-byte chunk slot of (row yr, x = 2 e + o, chunk c of the 8 channels) = ((yr * 2 + o) * E + e) * 2 + (c ^ swz(e, yr)),
+//   swz(e, yr) = ((e >> 3) + ((yr >> 1) & 1)) & 1
+// The 16 tiles of an MFMA row block are 16 consecutive e (stride-2 voxels of the dense row are consecutive here) and the
+// XOR spreads them over the sixteen 16-byte bank slots: the ds_read_b64 of a (tile, channel-pair) fragment is conflict
+// free within a tile row and nearly so across a row wrap.  The image is filled by LDS-DMA (buffer_load_dwordx4 ... lds:
+// no staging registers, no ds_write pass); the swizzle is on the source address, the LDS side is lane-linear.
+__device__ __forceinline__ int swz(int e, int yr) { return ((e >> 3) + ((yr >> 1) & 1)) & 1; }
+
+// One 8-channel sub-image of one input plane: wave-instruction j = wave + 8 i moves chunk slots 64 j .. 64 j + 63 (1 KB,
+// lane-linear) from the plane at `base`; offsets outside [0, span) arrive as zeros.
+template <int NI>
+__device__ __forceinline__ void dma_subimage(const float *base, int span, const int *voff, char *dst, int wave, int ndma) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, span, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = wave + 8 * i;
+    if (j < ndma)                                            // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, voff[i], 0, 0, 0);
+  }
+}
+
+// EP: compiled epilogue -- 0: LeakyReLU(slope) (forward layers); 1: LeakyReLU' gate on the saved activation (input-gradients);
+// 2: gate, the forward pass's dropout keep bits and a second output tensor (input-gradient of a concat through Dropout)
+template <int CI, int CO, int NI, int EP>
+__global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
+  constexpr int NH = CI / 8, VB = 32;                        // channel-pair halves = sub-images (8 channels); bytes per sub-image voxel
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char *const ring = reinterpret_cast<char *>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, q = lane >> 4;
+  const int grp = wave >> 1, zb = wave & 1;                  // 16-tile row block; output plane of the step
+  const float *const uld = reinterpret_cast<const float *>(ring + 4 * p.slotb);
+
+  int seg = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int zseg = seg % p.zsegs; seg /= p.zsegs;
+  const int bx = seg % p.nbx; seg /= p.nbx;
+  const int by = seg % p.nby;
+  const int n = seg / p.nby;
+  const int tz0 = zseg * p.zper, tz1 = min(p.NTZ, tz0 + p.zper), nsteps = tz1 - tz0;
+  const int oy0 = by * 2 * p.BY, ox0 = bx * 2 * p.BX;
+  const int ntile = p.BY * p.BX;
+
+  // ---- LDS-DMA: byte offset of the lane's chunk inside a z-plane of the source view, relative to the sub-image's first
+  // channel (the same for every sub-image and plane; recomputed per call -- a descriptor kept in registers across the
+  // step would be spilled, and its reload waits for the DMA in flight); out of range = zero padding / slot padding
+  const bool two_in = p.in1 != p.in0;                      // kernel-uniform
+  const float *const in0n = p.in0 + (size_t)n * p.i0N, *const in1n = p.in1 + (size_t)n * p.i1N;
+  auto dma_plane = [&](int iz, int slot) {                 // input plane iz -> ring slot (zeros outside the input)
+    const bool zok = (unsigned)iz < (unsigned)p.D;
+    const int izc = zok ? iz : 0;
+    const int iy0 = oy0 - p.P, ix0 = ox0 - p.P;
+    int voff0[NI], voff1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int sp = (wave + 8 * i) * 64 + lane;
+      asm volatile("" : "+v"(sp));
+      const bool ex = sp < p.PLC;
+      const int spc = ex ? sp : 0;
+      const int cpos = spc & 1, ve = spc >> 1;
+      const int ro = (int)fdiv((uint32_t)ve, (uint32_t)p.E, p.magicE), e = ve - ro * p.E;
+      const int o = ro & 1, yr = ro >> 1;
+      const int c = (cpos ^ swz(e, yr)) * 4;
+      const int iy = iy0 + yr, ix = ix0 + 2 * e + o;
+      const bool ok = ex && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      voff0[i] = ok ? (iy * p.i0H + ix * p.i0W + c) * 4 : (int)0x80000000;
+      voff1[i] = ok ? (iy * p.i1H + ix * p.i1W + c) * 4 : (int)0x80000000;
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      char *const dst = ring + slot * p.slotb + h * p.subb;
+      if (!two_in || 8 * h < p.C0)
+        dma_subimage<NI>(in0n + izc * p.i0D + 8 * h, zok ? p.span0 - 32 * h : 0, voff0, dst, wave, p.ndma);
+      else
+        dma_subimage<NI>(in1n + izc * p.i1D + (8 * h - p.C0), zok ? p.span1 - 4 * (8 * h - p.C0) : 0, voff1, dst, wave, p.ndma);
+    }
+  };
+
+  // ---- prologue: the four planes of the first step, U into LDS
+  const int izb0 = 2 * tz0 - p.P;
+  if (nsteps > 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_plane(izb0 + k, k);
+  }
+  {
+    constexpr int UF4 = 3 * NH * 16 * 64 * 2 / 4;
+    const float4 *us = reinterpret_cast<const float4 *>(p.u);
+    float4 *ud = reinterpret_cast<float4 *>(ring + 4 * p.slotb);
+    for (int i = tid; i < UF4; i += 512) ud[i] = us[i];
+  }
+  __syncthreads();
+
+  const int rowb = p.E * VB;                                 // bytes per (yr, o) row of a sub-image
+  const Ep32 &ep = p.ep;
+  float *const out0n = p.out0 + (size_t)n * p.o0N, *const out1n = EP == 2 ? p.out1 + (size_t)n * p.o1N : nullptr;
+  const float *const gaten = EP >= 1 ? ep.gate + (size_t)n * ep.gN : nullptr;
+  const bool in0c = EP != 2 || m < p.CO0;                    // this lane's channel goes to out0 (with the full epilogue)
+
+  // A role: this lane's (tile, channel pair) of the wave's row block
+  const int tA = min(grp * 16 + m, ntile - 1);
+  const int tyA = (int)fdiv((uint32_t)tA, (uint32_t)p.BX, p.magicBX), txA = tA - tyA * p.BX;
+  const int a0 = (4 * tyA * p.E + txA) * VB + (q & 1) * 8;
+  int cs[2][2];                                              // chunk byte offset for (e = tx + a, tile row ty + b)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) cs[a][b] = ((q >> 1) ^ swz(txA + a, 2 * (tyA + b))) * 16;
+
+  unsigned long long t_last = p.stamps ? clock64() : 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) do { if (p.stamps) { unsigned long long t_now = clock64(); t_sum[i] += t_now - t_last; t_last = t_now; } } while (0)
+  for (int step = 0; step < nsteps; ++step) {
+    const int tz = tz0 + step, oz = 2 * tz + zb, izb = 2 * tz - p.P;
+    const bool more = step + 1 < nsteps;
+    const int sA = (step & 1) ? 2 : 0;                     // ring slots of the step's input planes 0,1 (2,3 are in the other pair)
+    STAMP(0);                                              // barrier B / loop overhead
+
+    // gate values / keep bits of the lane's 16 outputs (4 tiles x 2x2 voxels of plane oz), fetched a whole step ahead of use
+    float gv[16];
+    uint32_t kb[16];
+    if (EP >= 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int t = grp * 16 + 4 * q + r;
+        asm volatile("" : "+v"(t));
+        const int ty = (int)fdiv((uint32_t)t, (uint32_t)p.BX, p.magicBX), tx = t - ty * p.BX;
+        const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+        const bool tok = m < CO && t < ntile && in0c && oz < p.OD;
+#pragma unroll
+        for (int o4 = 0; o4 < 4; ++o4) {
+          const int y = oy + (o4 >> 1), x = ox + (o4 & 1);
+          const bool okf = tok && y < p.OH && x < p.OW;
+          gv[r * 4 + o4] = gaten[okf ? oz * ep.gD + y * ep.gH + x * ep.gW + m : 0];
+          if (EP == 2) {
+            const uint32_t e = ((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (y + ep.doy)) * ep.dW + (x + ep.dox)) *
+                                   (uint32_t)p.CO0 + m;
+            kb[r * 4 + o4] = ep.keep_mask[okf ? (e >> 3) : 0];
+          }
+        }
+      }
+    }
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      // input plane zb + kz of the step: planes 0,1 live in slots sA, sA+1, planes 2,3 in the other pair
+      const int pl = zb + kz;
+      const char *plane = ring + ((pl < 2 ? sA : 2 - sA) + (pl & 1)) * p.slotb + a0;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        f32x2 v[4][4];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 4; ++dx)
+            v[dy][dx] = *reinterpret_cast<const f32x2 *>(plane + h * p.subb + (2 * dy + (dx & 1)) * rowb + (dx >> 1) * VB + cs[dx >> 1][dy >> 1]);
+        if (kz == 1 && h == NH - 1) {
+          // every wave is past the step's planes 0 and 1 (wave zb = 0 reads 0,1,2; zb = 1 reads 1,2,3 in this order):
+          // they make room for the next step's, whose DMA flies under the last third of the step and the epilogue
+          __syncthreads();
+          if (more && !(p.dbg & 4)) { dma_plane(izb + 4, sA); dma_plane(izb + 5, sA + 1); }
+        }
+        // input transform B^T d B on (y, x), both channels of the pair at once
+#pragma unroll
+        for (int a = 0; a < 4; ++a) bt4(v[a][0], v[a][1], v[a][2], v[a][3]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bt4(v[0][b], v[1][b], v[2][b], v[3][b]);
+        const float *uh = uld + ((kz * NH + h) * 16) * 128 + lane * 2;
+        f32x2 uf[16];
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt) uf[pt] = *reinterpret_cast<const f32x2 *>(uh + pt * 128);
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[pt >> 2][pt & 3].x, uf[pt].x, acc[pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[pt >> 2][pt & 3].y, uf[pt].y, acc[pt], 0, 0, 0);
+      }
+    }
+    STAMP(1);                                              // reads + transforms + MFMAs (+ ring hand-over)
+
+    // ---- output transform A^T M A on (y, x); lane = (channel m, tiles 4q .. 4q+3 of the row block: the f32x4 components)
+    f32x4 yx[4][2], yy[2][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) at4(acc[a * 4 + 0], acc[a * 4 + 1], acc[a * 4 + 2], acc[a * 4 + 3], yx[a][0], yx[a][1]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) at4(yx[0][b], yx[1][b], yx[2][b], yx[3][b], yy[0][b], yy[1][b]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int t = grp * 16 + 4 * q + r;
+      asm volatile("" : "+v"(t));
+      const int ty = (int)fdiv((uint32_t)t, (uint32_t)p.BX, p.magicBX), tx = t - ty * p.BX;
+      const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+      const bool tok = m < CO && t < ntile && oz < p.OD;
+#pragma unroll
+      for (int o4 = 0; o4 < 4; ++o4) {
+        const int y = oy + (o4 >> 1), x = ox + (o4 & 1);
+        const bool ok = tok && y < p.OH && x < p.OW;
+        float val = yy[o4 >> 1][o4 & 1][r];
+        if (EP == 0) val = val > 0.f ? val : ep.slope * val;
+        if (EP >= 1 && in0c) {
+          val = gv[r * 4 + o4] > 0.f ? val : ep.gate_slope * val;
+          if (EP == 2) {
+            const uint32_t e = ((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (y + ep.doy)) * ep.dW + (x + ep.dox)) *
+                                   (uint32_t)p.CO0 + m;
+            val = ((kb[r * 4 + o4] >> (e & 7u)) & 1u) ? 2.f * val : 0.f;
+          }
+        }
+        if (!(p.dbg & 1)) {
+          if (ok && in0c) out0n[oz * p.o0D + y * p.o0H + x * p.o0W + m] = val;
+          if (EP == 2 && ok && !in0c) out1n[oz * p.o1D + y * p.o1H + x * p.o1W + (m - p.CO0)] = val;
+        }
+      }
+    }
+    STAMP(2);                                              // output transform + epilogue
+    __syncthreads();
+  }
+  if (p.stamps && lane == 0) {
+    for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = t_sum[i];
+  }
+#undef STAMP
+}
+
+// ------------------------------------------------------------------------------------------ weights
+// U[kz]_p(ci,co) = sum_{ky,kx} G[py][ky] G[px][kx] w((kz,ky,kx), ci, co), stored in B-fragment order:
+//   u[(((kz*NH + h)*16 + p)*64 + (q*16 + co))*2 + j]  with  ci = 8h + 2q + j, NH = ci/8   (co >= C_out: 0)
+__global__ __launch_bounds__(256) void wino_weights_k(const float *theta, float *u, const tem_wino_layer *layers) {
+  const tem_wino_layer L = layers[blockIdx.x];
+  const int co = threadIdx.x & 15, ci = (threadIdx.x >> 4) + 16 * blockIdx.y;
+  if (ci >= L.ci) return;
+  const int NH = L.ci / 8;
+  const int h = ci >> 3, q = (ci & 7) >> 1, j = ci & 1;
+  auto g4 = [](float a, float b, float c, float (&o)[4]) {
+    o[0] = a; o[1] = 0.5f * (a + b + c); o[2] = 0.5f * (a - b + c); o[3] = c;
+  };
+#pragma unroll
+  for (int kz = 0; kz < 3; ++kz) {
+    float g[3][3];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int t = kz * 9 + t9;
+      float w = 0.f;
+      if (co < L.co) w = L.flip ? theta[L.src_off + ((int64_t)(26 - t) * L.co + co) * L.ci + ci]
+                                : theta[L.src_off + ((int64_t)t * L.ci + ci) * L.co + co];
+      g[t9 / 3][t9 % 3] = w;
+    }
+    float gx[3][4], gy[4][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g4(g[a][0], g[a][1], g[a][2], gx[a]);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      float o[4];
+      g4(gx[0][x], gx[1][x], gx[2][x], o);
+#pragma unroll
+      for (int y = 0; y < 4; ++y) gy[y][x] = o[y];
+    }
+    float *d = u + L.dst_off + ((int64_t)((kz * NH + h) * 16) * 64 + (q * 16 + co)) * 2 + j;
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt) d[pt * 128] = gy[pt >> 2][pt & 3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+constexpr int LDS_MAX = 160 * 1024;
+static thread_local char *g_name = nullptr;
+static thread_local int g_name_len = 0;
+
+static uint32_t magic_for(int d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
+
+static bool fits32(const tem_view &v) {
+  int64_t span = (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH +
+                 (int64_t)(v.W - 1) * v.sW + v.C;
+  return span < (int64_t)1 << 31 && v.sN < ((int64_t)1 << 31);
+}
+
+template <int CI, int CO, int NI>
+int plan(Dev &p, double *cost, size_t *lds_bytes) {
+  constexpr int NH = CI / 8;
+  const size_t ubytes = (size_t)3 * NH * 16 * 64 * 2 * 4;
+  const int TY = (p.OH + 1) / 2, TX = (p.OW + 1) / 2;
+  double best = 1e300;
+  for (int by = 1; by <= TY && by <= 64; ++by)
+    for (int bx = 1; bx <= TX && bx <= 64; ++bx) {
+      const int nt = by * bx;
+      if (nt > 64) continue;
+      const int E = bx + 1, plv = (2 * by + 2) * 2 * E;
+      const int subb = (plv * 32 + 1023) & ~1023, slotb = NH * subb;
+      const size_t bytes = (size_t)4 * slotb + ubytes;
+      const int ndma = subb / 1024;
+      if (bytes > (size_t)LDS_MAX || ndma > 8 * NI) continue;
+      const int nby = (TY + by - 1) / by, nbx = (TX + bx - 1) / bx;
+      const int cols = p.N * nby * nbx;
+      // cycles per step and SIMD: the MFMA stream of its two waves (3 z taps x NH x 32 each, 45 reference cycles per
+      // MFMA at the throttled matrix clock) with the transforms / stores of one wave under the other's -- a SIMD with
+      // ONE busy wave (<= 2 row blocks) takes as long, its latencies exposed (measured); a row block that wraps tile
+      // rows pays a few LDS bank conflicts; prologue = four planes + U at the CU's HBM share
+      const int wraps = (16 % bx) ? 1 : 0;
+      const double step = 2.0 * 3 * NH * 32 * 45.0 * (1.0 + 0.03 * wraps) + 3500.0;
+      const double pro = 6000.0 + (4.0 * slotb + ubytes) / 10.0;
+      for (int zs = 1; zs <= p.NTZ; ++zs) {
+        const int zper = (p.NTZ + zs - 1) / zs, zsegs = (p.NTZ + zper - 1) / zper;
+        if (zsegs != zs) continue;
+        const double t = std::ceil(cols * zsegs / 256.0) * (pro + zper * step);
+        if (t < best) {
+          best = t; p.BY = by; p.BX = bx; p.nby = nby; p.nbx = nbx; p.zsegs = zsegs; p.zper = zper;
+          p.E = E; p.PLC = plv * 2; p.subb = subb; p.slotb = slotb; p.ndma = ndma; *lds_bytes = (bytes + 15) & ~(size_t)15;
+        }
+      }
+    }
+  *cost = best;
+  return best < 1e300 ? TEM_OK : TEM_EUNSUPPORTED;
+}
+
+template <int CI, int CO, int NI, int EP>
+int run_best(Dev p, hipStream_t st, bool dry) {
+  double c1 = 1e300;
+  size_t lds_bytes = 0;
+  if (plan<CI, CO, NI>(p, &c1, &lds_bytes) != TEM_OK) return TEM_EUNSUPPORTED;
+  p.magicBX = magic_for(p.BX); p.magicE = magic_for(p.E);
+  if (dry) {
+    if (g_name) snprintf(g_name, g_name_len, "wino_conv_k<%d, %d, %d, %d>", CI, CO, NI, EP);
+    return TEM_OK;
+  }
+  const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
+  if (p.dbg & 8)
+    fprintf(stderr, "wino<%d,%d,%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI, CO, EP,
+            p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
+  auto kern = wino_conv_k<CI, CO, NI, EP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds_bytes, st, p);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
+  const tem_view &i0 = a->in0, &o0 = a->out0;
+  const bool cube = a->kd == 3 && a->kh == 3 && a->kw == 3 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->pd == a->ph &&
+                    a->ph == a->pw;
+  if (!cube || a->w_layout != TEM_W_WINOGRAD || a->pd < 0) return TEM_EUNSUPPORTED;
+  if (!fits32(i0) || !fits32(o0)) return TEM_EUNSUPPORTED;
+  Dev p{};
+  p.in0 = i0.ptr; p.i0N = (int)i0.sN; p.i0D = (int)i0.sD; p.i0H = (int)i0.sH; p.i0W = (int)i0.sW; p.C0 = i0.C;
+  p.in1 = i0.ptr; p.i1N = p.i0N; p.i1D = p.i0D; p.i1H = p.i0H; p.i1W = p.i0W;
+  int CI = i0.C;
+  auto aligned = [](const tem_view &v) {
+    return ((uintptr_t)v.ptr & 15) == 0 && v.sW % 4 == 0 && v.sH % 4 == 0 && v.sD % 4 == 0 && v.sN % 4 == 0 && v.C % 4 == 0;
+  };
+  if (!aligned(i0)) return TEM_EUNSUPPORTED;
+  if (a->in1.ptr) {
+    const tem_view &i1 = a->in1;
+    if (i1.N != i0.N || i1.D != i0.D || i1.H != i0.H || i1.W != i0.W) return TEM_ESHAPE;
+    if (!fits32(i1) || !aligned(i1)) return TEM_EUNSUPPORTED;
+    p.in1 = i1.ptr; p.i1N = (int)i1.sN; p.i1D = (int)i1.sD; p.i1H = (int)i1.sH; p.i1W = (int)i1.sW;
+    CI += i1.C;
+    if (i0.C % 8) return TEM_EUNSUPPORTED;                 // a sub-image (8 channels) has one source
+  }
+  p.N = i0.N; p.D = i0.D; p.H = i0.H; p.W = i0.W;
+  p.span0 = (int)(((int64_t)(i0.H - 1) * p.i0H + (int64_t)(i0.W - 1) * p.i0W + i0.C) * 4);
+  p.span1 = a->in1.ptr ? (int)(((int64_t)(i0.H - 1) * p.i1H + (int64_t)(i0.W - 1) * p.i1W + a->in1.C) * 4) : p.span0;
+  p.u = a->w;
+  p.out0 = o0.ptr; p.o0N = (int)o0.sN; p.o0D = (int)o0.sD; p.o0H = (int)o0.sH; p.o0W = (int)o0.sW; p.CO0 = o0.C;
+  int CO = o0.C;
+  if (a->out1.ptr) {
+    const tem_view &o1 = a->out1;
+    if (o1.N != o0.N || o1.D != o0.D || o1.H != o0.H || o1.W != o0.W) return TEM_ESHAPE;
+    if (!fits32(o1)) return TEM_EUNSUPPORTED;
+    p.out1 = o1.ptr; p.o1N = (int)o1.sN; p.o1D = (int)o1.sD; p.o1H = (int)o1.sH; p.o1W = (int)o1.sW;
+    CO += o1.C;
+  }
+  if (o0.N != i0.N) return TEM_ESHAPE;
+  if (o0.D != i0.D + 2 * a->pd - 2 || o0.H != i0.H + 2 * a->ph - 2 || o0.W != i0.W + 2 * a->pw - 2) return TEM_ESHAPE;
+  p.OD = o0.D; p.OH = o0.H; p.OW = o0.W;
+  p.NTZ = (p.OD + 1) / 2;
+  p.P = a->pd;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
+    p.dbg = dbg;
+    static unsigned long long stamp_ptr = ~0ull;
+    if (stamp_ptr == ~0ull) { const char *v = getenv("TEM_WINO_STAMP_BUF"); stamp_ptr = v ? strtoull(v, nullptr, 16) : 0; }
+    p.stamps = (unsigned long long *)stamp_ptr;
+  }
+  const tem_epilogue &e = a->ep;
+  Ep32 &q = p.ep;
+  if (e.bias || e.add.ptr) return TEM_EUNSUPPORTED;        // no k3 s1 layer of the step has them
+  q.slope = e.slope; q.gate_slope = e.gate_slope;
+  int EP = 0;
+  if (e.gate.ptr) {
+    const tem_view &g = e.gate;
+    if (g.N != o0.N || g.D != o0.D || g.H != o0.H || g.W != o0.W || g.C < o0.C) return TEM_ESHAPE;
+    if (!fits32(g) || e.slope != 1.f) return TEM_EUNSUPPORTED;
+    q.gate = g.ptr; q.gN = (int)g.sN; q.gD = (int)g.sD; q.gH = (int)g.sH; q.gW = (int)g.sW;
+    EP = 1;
+  }
+  if (e.dropout || a->out1.ptr) {
+    // only the pair the step uses: the forward pass's keep bits (the Philox form would cost one block per element here)
+    // together with the split output, behind a gate
+    if (!(e.dropout && e.keep_mask && e.keep_mode == 2 && a->out1.ptr && EP == 1)) return TEM_EUNSUPPORTED;
+    q.keep_mask = e.keep_mask;
+    q.doz = e.drop_org[0]; q.doy = e.drop_org[1]; q.dox = e.drop_org[2];
+    q.dD = e.drop_dims[0] ? e.drop_dims[0] : o0.D; q.dH = e.drop_dims[0] ? e.drop_dims[1] : o0.H;
+    q.dW = e.drop_dims[0] ? e.drop_dims[2] : o0.W;
+    if ((int64_t)o0.N * q.dD * q.dH * q.dW * o0.C >= ((int64_t)1 << 32)) return TEM_EUNSUPPORTED;
+    EP = 2;
+  }
+#define WINO_CASE(ci, co, ni, epi) if (CI == ci && CO == co && EP == epi) return run_best<ci, co, ni, epi>(p, st, dry);
+  WINO_CASE(16, 16, 2, 0) WINO_CASE(16, 16, 2, 1) WINO_CASE(16, 16, 2, 2)
+  WINO_CASE(8, 8, 2, 0) WINO_CASE(8, 8, 2, 1)
+  WINO_CASE(8, 16, 2, 0) WINO_CASE(8, 16, 2, 1)
+  WINO_CASE(16, 8, 2, 0) WINO_CASE(16, 8, 2, 1)
+#undef WINO_CASE
+  return TEM_EUNSUPPORTED;
+}
+
+}  // namespace wino
+
+int tem_conv_wino_try(const tem_conv_args *a, hipStream_t st, bool dry) { return wino::dispatch(a, st, dry); }
+
+int tem_conv_wino_describe(const tem_conv_args *a, char *buf, int len) {
+  wino::g_name = buf; wino::g_name_len = len;
+  int rc = wino::dispatch(a, nullptr, true);
+  wino::g_name = nullptr;
+  return rc;
+}
+
+extern "C" int tem_winograd_weights(const float *theta, float *u, const tem_wino_layer *layers_dev, int32_t nlayers,
+                                    tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!theta || !u || !layers_dev || nlayers <= 0) return TEM_EINVAL;
+  hipLaunchKernelGGL(wino::wino_weights_k, dim3(nlayers, 2), dim3(256), 0, (hipStream_t)stream, theta, u, layers_dev);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import tem_view, tem_conv_args, tem_bww_args, TEM_W_TAP_CI_CO, TEM_W_FLIP_CO_CI  # noqa: F401
+from ._lib import tem_view, tem_conv_args, tem_bww_args, TEM_W_TAP_CI_CO, TEM_W_FLIP_CO_CI, TEM_W_WINOGRAD  # noqa: F401
 
 LEAKY = 0.3            # tf.keras.layers.LeakyReLU() default alpha (reference models/utils.py:77)
 NULL_VIEW = tem_view()
@@ -84,9 +84,11 @@ def _p3(p, is3d):
 
 def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=None, layout=TEM_W_TAP_CI_CO,
                 transposed=False, slope=1.0, bias=None, gate=None, gate_slope=LEAKY, add=None, add_off=0,
-                dropout=None, drop_frame=None, keep_mask=None, direct=False):
+                dropout=None, drop_frame=None, keep_mask=None, direct=False, wino=None):
     """Build a tem_conv / tem_conv_transpose launch.  `w` and `bias` are 1-D float32 tensors
-    (slices of a network's flat parameter vector); dropout = (seed, site, step_dev_tensor)."""
+    (slices of a network's flat parameter vector); dropout = (seed, site, step_dev_tensor).
+    wino: the layer's Winograd-domain kernel copy (ParamSet.u); used instead of `w` when the library runs this
+    geometry and epilogue in the Winograd form (tem_conv_is_tiled with TEM_W_WINOGRAD), ignored otherwise."""
     lib = _lib.load()
     a = tem_conv_args()
     keep = [in0, w, out0]
@@ -127,6 +129,12 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
             ep.keep_mask, ep.keep_mode = mask.data_ptr(), int(mode)
             keep.append(mask)
     bf16 = in0.dtype == torch.bfloat16
+    if wino is not None and not bf16 and not transposed and not direct:
+        a.w, a.w_layout = wino.data_ptr(), TEM_W_WINOGRAD
+        if lib.tem_conv_is_tiled(C.byref(a), 0, None, 0) == 1:
+            keep.append(wino)
+        else:
+            a.w, a.w_layout = w.data_ptr(), layout
     if bf16:
         # bf16 mixed precision (BASELINE config 5): bf16 activations / gate / add views, `w` = bf16 kernel packed
         # [tap][co][ci] (ParamSet.theta_h / theta_ht), fp32 accumulation and epilogue (tem_conv_bf16)
@@ -155,9 +163,10 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
     elif transposed:
         kern = f"convT_direct_k<{ci0}, {co0}, {co1}, {8 if co0 + co1 == 32 else co0 + co1}>"
     else:
-        kern = f"conv_direct_k<{ci0}, {ci1}, {co0}, {co1}, {'true' if layout == TEM_W_FLIP_CO_CI else 'false'}>"
+        kern = f"conv_direct_k<{ci0}, {ci1}, {co0}, {co1}, {'true' if a.w_layout == TEM_W_FLIP_CO_CI else 'false'}>"
     meta = dict(flops=2.0 * ntap * ci * co * (vin if transposed else vout),
-                bytes=esz * (ci * vin + co * vout) + 4.0 * ntap * ci * co, kernel=kern)
+                bytes=esz * (ci * vin + co * vout) + 4.0 * ntap * ci * co, kernel=kern,
+                shape=f"{ci0}+{ci1}@{tuple(in0.shape[:4])} -> {co0}+{co1}@{tuple(out0.shape[:4])} k{k} s{s} p{p}")
     return Launch(fn, (C.byref(a),), name, keep + [a], meta)
 
 
@@ -360,6 +369,30 @@ def flip_transpose_launch(name, theta, theta_t, table_dev, nlayers):
     lib = _lib.load()
     return Launch(lib.tem_flip_transpose, (theta.data_ptr(), theta_t.data_ptr(), table_dev.data_ptr(), nlayers,
                                            theta.numel()), name, [theta, theta_t, table_dev])
+
+
+def wino_table(entries, device):
+    """Device table of tem_wino_layer records from (src_off, dst_off, ci, co, flip) tuples (uint8 tensor)."""
+    arr = (_lib.tem_wino_layer * len(entries))()
+    for r, e in zip(arr, entries):
+        r.src_off, r.dst_off, r.ci, r.co, r.flip = e
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+def wino_weights_launch(name, theta, u, table_dev, nlayers):
+    """u := Winograd-domain copies of the listed 3x3x3 kernels of theta (tem_winograd_weights)."""
+    lib = _lib.load()
+    return Launch(lib.tem_winograd_weights, (theta.data_ptr(), u.data_ptr(), table_dev.data_ptr(), nlayers), name,
+                  [theta, u, table_dev])
+
+
+WINO_U_FLOATS = 6144          # floats of the Winograd-domain copy of one 3x3x3 kernel per 8 input channels (tem_wino_layer)
+
+
+def wino_channels(ci, co):
+    """Channel pairs (of the OPERATOR: the input-gradient of a ci -> co layer is a co -> ci operator) that the Winograd
+    kernel is built for and wins on (8 -> 8 stays on the direct VALU kernel: half of every MFMA tile would be empty)."""
+    return (ci, co) in ((16, 16), (8, 16), (16, 8))
 
 
 def pack_weights_launch(name, theta, theta_h, theta_ht, table_dev, nlayers):

@@ -70,7 +70,7 @@ _SLOPE = {"d3b": DOUBLE_LEAKY, "p2": 1.0}
 
 
 class DiscForward:
-    def __init__(self, net, x, direct=False):
+    def __init__(self, net, x, direct=False, refresh_u=True):
         P, is3d = net.params, net.is3d
         self.net, self.x = net, x
         self.dtype = x.dtype
@@ -86,6 +86,8 @@ class DiscForward:
         L = self.launches = []
         prev = x
         self.prior_fwd = None
+        if not bf and refresh_u and P.winograd_launch() is not None:
+            L.append(P.winograd_launch("d.winograd"))     # stand-alone plan (see GenForward)
         for name in self.order:
             n = e[name]
             if n < 1:
@@ -105,7 +107,8 @@ class DiscForward:
             L.append(H.conv_launch("d." + name, prev, P.wht(name) if bf else P.w(name), A[name], k, s, 0,
                                    is3d=is3d if k > 1 else True,
                                    in1=in1, slope=_SLOPE.get(name, H.LEAKY),
-                                   bias=P.w("p2_bias") if name == "p2" else None, direct=direct))
+                                   bias=P.w("p2_bias") if name == "p2" else None, direct=direct,
+                                   wino=None if (bf or direct or in1 is not None) else P.u(name)))
             prev = A[name]
         self.z = A["p2"]
 
@@ -157,7 +160,8 @@ class DiscBackward:
                                        dst, k, 1, k - 1,
                                        is3d=i3, out1=g_feat if with_prior else None,
                                        layout=H.TEM_W_TAP_CI_CO if use_t else H.TEM_W_FLIP_CO_CI,
-                                       gate=gate, gate_slope=gslope, direct=direct))
+                                       gate=gate, gate_slope=gslope, direct=direct,
+                                       wino=None if (bf or direct or with_prior) else P.u(name, bwd=True)))
             else:
                 L.append(H.conv_launch("d.bd." + name, g_out, P.wh(name) if bf else P.w(name), dst, k, s, 0, is3d=i3,
                                        transposed=True,

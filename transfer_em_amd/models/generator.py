@@ -132,7 +132,7 @@ class GenForward:
     activation buffer then holds the region R[layer] of its logical tensor and the operators get the
     correspondingly shifted padding (conv: p' = p + lo_in - s*lo_out, transposed: p' = p + lo_out - s*lo_in)."""
 
-    def __init__(self, net, x, in_pad=0, training=False, drop=None, out_crop=0, direct=False, pack=False):
+    def __init__(self, net, x, in_pad=0, training=False, drop=None, out_crop=0, direct=False, pack=False, refresh_u=True):
         P, is3d = net.params, net.is3d
         self.net, self.x, self.in_pad, self.training, self.drop = net, x, in_pad, training, drop
         # bf16 mixed precision (BASELINE config 5): `x` and every activation are bf16, the kernels read the per-step
@@ -181,11 +181,15 @@ class GenForward:
         L = self.launches = []
         if bf and pack:                               # stand-alone plan (inference): refresh the bf16 kernel copies itself
             L.append(P.pack_bf16_launch("g.pack_bf16"))
+        if not bf and refresh_u and P.winograd_launch() is not None:
+            L.append(P.winograd_launch("g.winograd"))     # stand-alone plan: refresh the Winograd-domain kernel copies
+                                                          # (the train step does it once per network instead)
+        wu = (lambda name: None) if (bf or direct) else P.u
         cv = H.conv_launch
         L.append(cv("g.c0", x, wf("c0"), A["c0"], 3, 1, pc(in_pad, 1, "", "c0"), slope=H.LEAKY, **kw))
         L.append(cv("g.d1a", A["c0"], wf("d1a"), A["d1a"], 3, 1, pc(0, 1, "c0", "d1a"), slope=H.LEAKY, **kw))
         L.append(cv("g.d1b", A["d1a"], wf("d1b"), A["d1b"], 4, 2, pc(0, 2, "d1a", "d1b"), slope=H.LEAKY, **kw))
-        L.append(cv("g.d2a", A["d1b"], wf("d2a"), A["d2a"], 3, 1, pc(0, 1, "d1b", "d2a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d2a", A["d1b"], wf("d2a"), A["d2a"], 3, 1, pc(0, 1, "d1b", "d2a"), slope=H.LEAKY, wino=wu("d2a"), **kw))
         L.append(cv("g.d2b", A["d2a"], wf("d2b"), A["d2b"], 4, 2, pc(0, 2, "d2a", "d2b"), slope=H.LEAKY, **kw))
         L.append(cv("g.u2a", A["d2b"], wf("u2a"), A["u2a"], 3, 1, pc(0, 1, "d2b", "u2a"), slope=H.LEAKY, **kw))
         L.append(cv("g.u2b", A["u2a"], wT("u2b"), A["u2b"], 4, 2, pt(1, 2, "u2a", "u2b"), transposed=True,
@@ -196,7 +200,7 @@ class GenForward:
         L.append(cv("g.u1b", A["u1a"], wT("u1b"), A["u1b"], 4, 2, pt(1, 2, "u1a", "u1b"), transposed=True,
                     slope=H.LEAKY, dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), keep_mask=km(1, 1), **kw))
         L.append(cv("g.f1", A["u1b"], wf("f1"), A["f1"], 3, 1, pc(0, 1, "u1b", "f1"), in1=self.skip0,
-                    slope=H.LEAKY, **kw))
+                    slope=H.LEAKY, wino=wu("f1"), **kw))
         L.append(cv("g.f2", A["f1"], wf("f2"), A["f2"], 3, 1, pc(0, 1, "f1", "f2"), slope=1.0, **kw))
         self.y = A["f2"]                                   # window [out_crop, out - out_crop) of the logical output
 
@@ -257,7 +261,8 @@ class GenBackward:
 
         def cvb(lname, gin, name, gout, pad, **k2):
             wsel = wb(name)
-            return cv(lname, gin, wsel["w"], gout, 3, 1, pad, layout=wsel["layout"], **k2)
+            wn = None if (bf or direct) else P.u(name, bwd=True)
+            return cv(lname, gin, wsel["w"], gout, 3, 1, pad, layout=wsel["layout"], wino=wn, **k2)
         # every input-gradient of a stride-1 VALID conv is a conv with pad k-1 = 2 over the output gradient
         L.append(bww("f2", A["f1"], dy, 3, 1, pc(0, 1, "f1", "f2")))
         L.append(cvb("g.bd.f2", dy, "f2", G["f1"], pc(2, 1, "f2", "f1"), gate=A["f1"], **kw))

@@ -38,6 +38,22 @@ class ParamSet:
         self._wtable = torch.from_numpy(host.view(np.uint8).copy()).to(self.device)
         self._nlayers = len(tab)
         self.theta_h = self.theta_ht = None          # bf16 kernel copies (mixed precision), made on demand
+        # Winograd-domain copies (tem_winograd_weights) of the 3x3x3 kernels whose forward and / or input-gradient
+        # operator runs in the Winograd form: name -> element offset in theta_u, for the layer as a forward operator
+        # (_u_fwd) and as its input-gradient (_u_bwd: taps reversed, channels swapped); refreshed with theta_t
+        from .. import hip_ops as H
+        ents, off = [], 0
+        self._u_fwd, self._u_bwd = {}, {}
+        for k, s_ in self.shapes.items():
+            if len(s_) == 5 and tuple(s_[:3]) == (3, 3, 3):
+                ci, co = int(s_[3]), int(s_[4])
+                if H.wino_channels(ci, co):
+                    self._u_fwd[k] = off; ents.append((self.offsets[k], off, ci, co, 0)); off += (ci // 8) * H.WINO_U_FLOATS
+                if H.wino_channels(co, ci):
+                    self._u_bwd[k] = off; ents.append((self.offsets[k], off, co, ci, 1)); off += (co // 8) * H.WINO_U_FLOATS
+        self._u_entries = ents
+        self.theta_u = torch.zeros(max(off, 1), dtype=torch.float32, device=self.device)
+        self._utable = H.wino_table(ents, self.device) if ents else None
         self.initialize(seed)
 
     def initialize(self, seed=None):
@@ -86,9 +102,35 @@ class ParamSet:
         self.enable_bf16()
         return H.pack_weights_launch(name, self.theta, self.theta_h, self.theta_ht, self._wtable, self._nlayers)
 
-    def flip_transpose_launch(self, name="flip_transpose"):
+    def u(self, name, bwd=False):
+        """1-D slice of theta_u: Winograd-domain copy of kernel `name` (as a forward operator, or bwd=True as its
+        input-gradient operator), or None if that operator is not built in the Winograd form."""
         from .. import hip_ops as H
-        return H.flip_transpose_launch(name, self.theta, self.theta_t, self._wtable, self._nlayers)
+        o = (self._u_bwd if bwd else self._u_fwd).get(name)
+        if o is None:
+            return None
+        s_ = self.shapes[name]
+        return self.theta_u[o:o + (int(s_[4] if bwd else s_[3]) // 8) * H.WINO_U_FLOATS]
+
+    def winograd_launch(self, name="winograd"):
+        """Refresh theta_u from theta (None if the network has no Winograd layer)."""
+        from .. import hip_ops as H
+        if self._utable is None:
+            return None
+        return H.wino_weights_launch(name, self.theta, self.theta_u, self._utable, len(self._u_entries))
+
+    def flip_transpose_launch(self, name="flip_transpose"):
+        """Once per step, after the optimizer update: the kernel copies derived from theta (theta_t and theta_u)."""
+        from .. import hip_ops as H
+        ft = H.flip_transpose_launch(name, self.theta, self.theta_t, self._wtable, self._nlayers)
+        wl = self.winograd_launch(name + ".winograd")
+        if wl is None:
+            return ft
+
+        def both(stream):
+            rc = ft.fn(*ft.args, stream)
+            return rc or wl.fn(*wl.args, stream)
+        return H.Launch(both, (), name, [ft, wl], dict(ft.meta))
 
     def g(self, name):
         o = self.offsets[name]
