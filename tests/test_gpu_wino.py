@@ -95,3 +95,43 @@ def test_winograd_falls_back_when_unsupported():
     l = H.conv_launch("c", x16, th16, out16, 3, 1, 0, slope=0.3, bias=bias, wino=torch.zeros(2 * H.WINO_U_FLOATS, device=dev))
     assert not l.meta["kernel"].startswith("wino_conv_k")                           # bias: not in the Winograd epilogues
     H.run([l]); torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("ci0,ci1,n,pad", [(8, 8, 13, 0), (16, 0, 10, 0), (8, 0, 11, 0), (16, 0, 9, 2)])
+def test_winograd_kernel_gradient_matches_oracle(ci0, ci1, n, pad):
+    """tem_conv_bwd_weight_winograd (one slab, deterministic) against the oracle's float64 kernel gradient."""
+    import ctypes as C
+    from transfer_em_amd import hip_ops as H, _lib
+    from oracle import ops as O
+    H.require_gpu()
+    rng = np.random.default_rng(11)
+    ci, co = ci0 + ci1, 16
+    x = rng.standard_normal((2, n, n + 3, n + 4, ci)).astype(np.float32)
+    od = (n + 2 * pad - 2, n + 3 + 2 * pad - 2, n + 4 + 2 * pad - 2)
+    g = rng.standard_normal((2,) + od + (co,)).astype(np.float32)
+    ref = O.conv_bwd_weight(x, g, (3, 3, 3), 1, pad)
+    dev = "cuda"
+    lib = _lib.load()
+    xd, gd = torch.from_numpy(x).to(dev), torch.from_numpy(g).to(dev)
+    a = _lib.tem_bww_args()
+    a.in0 = H.view(xd[..., :ci0])
+    if ci1:
+        a.in1 = H.view(xd[..., ci0:])
+    a.dout = H.view(gd)
+    a.kd = a.kh = a.kw = 3; a.sd = a.sh = a.sw = 1; a.pd = a.ph = a.pw = pad
+    name = C.create_string_buffer(64)
+    nws = lib.tem_conv_bwd_weight_winograd_ws(C.byref(a), name, 64)
+    assert nws > 0 and name.value.decode().startswith("wino_bww_k"), (nws, name.value)
+    scratch = torch.empty(int(nws), device=dev)
+    outs = []
+    for _ in range(2):                                                   # twice: the sums are order-deterministic
+        slab = torch.full((27 * ci * co,), float("nan"), device=dev)
+        a.slabs, a.nslab, a.accumulate = slab.data_ptr(), 1, 0
+        rc = lib.tem_conv_bwd_weight_winograd(C.byref(a), scratch.data_ptr(), H.current_stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append(slab.cpu().numpy().reshape(3, 3, 3, ci, co))
+    assert np.array_equal(outs[0], outs[1])
+    err = np.abs(outs[0] - ref).max()
+    assert err <= 3e-6 * np.abs(ref).max() + 1e-4, (err, np.abs(ref).max())
+    assert np.linalg.norm(outs[0] - ref) <= 3e-6 * np.linalg.norm(ref)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "tem_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(tem_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\bint(?:64_t)?\s+(tem_\w+)\s*\(", src)))
 
 
 def test_header_and_binding_agree():

@@ -66,7 +66,7 @@ for name, (ci0, ci1), (co0, co1), nin, pad, flip, kw in cases:
     if stamps is not None:
         stamps.zero_(); H.run([lw]); torch.cuda.synchronize()
         st = stamps.view(-1, 8, 8).cpu().double(); nb = int((st.sum((1, 2)) > 0).sum())
-        names = ["loop/barB", "main", "epilogue", "-", "-", "-", "-", "-"]
+        names = ["loop/barB", "main", "late epi", "early epi", "-", "-", "-", "-"]
         print("   blocks", nb, " per-wave cycle sums (mean over waves): " + ", ".join(f"{nm} {st[:nb, :, i].mean():.0f}" for i, nm in enumerate(names)),
               f" total {st[:nb].sum(2).mean():.0f}")
     ur, uw = t([lref]), t([lw])

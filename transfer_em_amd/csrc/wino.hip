@@ -28,14 +28,12 @@
 // Conv3DBackpropInput.  fp32 throughout; the result differs from the direct form by rounding only
 // (|err| ~ 1e-6 relative, tests/test_gpu_wino.py), inside north_star's 1e-3.
 #include "tem_common.h"
+#include "wino_common.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
 namespace wino {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Ep32 {
   float slope;
@@ -64,42 +62,6 @@ struct Dev {
   unsigned long long *stamps;    // diagnostic: per-phase cycle sums [block][wave][8] (null in normal runs)
   Ep32 ep;
 };
-
-__device__ __forceinline__ uint32_t fdiv(uint32_t x, uint32_t d, uint32_t magic) { return d == 1 ? x : __umulhi(x, magic); }
-
-// 1-D transforms of F(2,3)
-template <typename T> __device__ __forceinline__ void bt4(T &a, T &b, T &c, T &d) {   // B^T
-  const T v0 = a - c, v1 = b + c, v2 = c - b, v3 = b - d;
-  a = v0; b = v1; c = v2; d = v3;
-}
-template <typename T> __device__ __forceinline__ void at4(const T &a, const T &b, const T &c, const T &d, T &y0, T &y1) {   // A^T
-  const T s = b + c, t = b - c;
-  y0 = a + s; y1 = t - d;
-}
-
-// LDS image of one input plane (YR = 2 BY + 2 rows of 2 E voxels): one sub-image per 8 input channels (= per channel-pair
-// half h of the k loop; a concat input's two sources land in different sub-images), rows split into their even-x and
-// odd-x voxels:
-//   16-byte chunk slot of (row yr, x = 2 e + o, chunk c of the 8 channels) = ((yr * 2 + o) * E + e) * 2 + (c ^ swz(e, yr)),
-//   swz(e, yr) = ((e >> 3) + ((yr >> 1) & 1)) & 1
-// The 16 tiles of an MFMA row block are 16 consecutive e (stride-2 voxels of the dense row are consecutive here) and the
-// XOR spreads them over the sixteen 16-byte bank slots: the ds_read_b64 of a (tile, channel-pair) fragment is conflict
-// free within a tile row and nearly so across a row wrap.  The image is filled by LDS-DMA (buffer_load_dwordx4 ... lds:
-// no staging registers, no ds_write pass); the swizzle is on the source address, the LDS side is lane-linear.
-__device__ __forceinline__ int swz(int e, int yr) { return ((e >> 3) + ((yr >> 1) & 1)) & 1; }
-
-// One 8-channel sub-image of one input plane: wave-instruction j = wave + 8 i moves chunk slots 64 j .. 64 j + 63 (1 KB,
-// lane-linear) from the plane at `base`; offsets outside [0, span) arrive as zeros.
-template <int NI>
-__device__ __forceinline__ void dma_subimage(const float *base, int span, const int *voff, char *dst, int wave, int ndma) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, span, 0x00020000);
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int j = wave + 8 * i;
-    if (j < ndma)                                            // wave-uniform
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, voff[i], 0, 0, 0);
-  }
-}
 
 // EP: compiled epilogue -- 0: LeakyReLU(slope) (forward layers); 1: LeakyReLU' gate on the saved activation (input-gradients);
 // 2: gate, the forward pass's dropout keep bits and a second output tensor (input-gradient of a concat through Dropout)
@@ -190,38 +152,88 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
 
   unsigned long long t_last = p.stamps ? clock64() : 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i) do { if (p.stamps) { unsigned long long t_now = clock64(); t_sum[i] += t_now - t_last; t_last = t_now; } } while (0)
+  // Waves 4..7 ("late") share their SIMDs with waves 0..3: they run a step's output transform / epilogue (vector pipe,
+  // stores) at the START of the next step, while their SIMD partner streams MFMAs, and stream their own MFMAs while the
+  // partner runs its epilogue at the END of its step -- the two pipes of a SIMD stay busy across the step boundary.
+  const bool late = (p.dbg & 32) ? wave >= 4 : false;      // measured: no gain (the barriers re-serialise the waves; one wave alone fills 45 % of the matrix pipe); kept for experiments
+  f32x4 acc[16];
+  float gv[16];                                            // gate values / keep-bit bytes of the lane's 16 outputs
+  uint32_t kb[16];                                         //   (4 tiles x 2x2 voxels of one plane), fetched a step ahead of use
+  // per tile r of the lane: offsets of its voxel (0, 0) in the output / gate / dropout frames and a validity mask
+  auto tile_geom = [&](int r, int oz, int &o0, int &o1, int &go, uint32_t &e0, uint32_t &okm) {
+    int t = grp * 16 + 4 * q + r;
+    asm volatile("" : "+v"(t));                              // per-use recompute: nothing per-tile stays in registers
+    const int ty = (int)fdiv((uint32_t)t, (uint32_t)p.BX, p.magicBX), tx = t - ty * p.BX;
+    const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+    const bool tok = m < CO && t < ntile && oz < p.OD;
+    okm = 0;
+#pragma unroll
+    for (int o4 = 0; o4 < 4; ++o4) okm |= ((tok && oy + (o4 >> 1) < p.OH && ox + (o4 & 1) < p.OW) ? 1u : 0u) << o4;
+    o0 = oz * p.o0D + oy * p.o0H + ox * p.o0W + m;
+    o1 = EP == 2 ? oz * p.o1D + oy * p.o1H + ox * p.o1W + (m - p.CO0) : 0;
+    go = EP >= 1 ? oz * ep.gD + oy * ep.gH + ox * ep.gW + m : 0;
+    e0 = EP == 2 ? ((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint32_t)p.CO0 + m : 0u;
+  };
+  auto fetch_ep = [&](int oz) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int o0, o1, go;
+      uint32_t e0, okm;
+      tile_geom(r, oz, o0, o1, go, e0, okm);
+      if (!in0c) okm = 0;
+#pragma unroll
+      for (int o4 = 0; o4 < 4; ++o4) {
+        const bool okf = (okm >> o4) & 1u;
+        gv[r * 4 + o4] = gaten[okf ? go + (o4 >> 1) * ep.gH + (o4 & 1) * ep.gW : 0];
+        if (EP == 2) {
+          const uint32_t e = e0 + ((o4 >> 1) * ep.dW + (o4 & 1)) * (uint32_t)p.CO0;
+          kb[r * 4 + o4] = ep.keep_mask[okf ? (e >> 3) : 0];
+        }
+      }
+    }
+  };
+  // output transform A^T M A on (y, x) and epilogue of plane oz; lane = (channel m, tiles 4q .. 4q+3 of the row block: the
+  // f32x4 components of the accumulators)
+  auto finish = [&](int oz) {
+    f32x4 yx[4][2], yy[2][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) at4(acc[a * 4 + 0], acc[a * 4 + 1], acc[a * 4 + 2], acc[a * 4 + 3], yx[a][0], yx[a][1]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) at4(yx[0][b], yx[1][b], yx[2][b], yx[3][b], yy[0][b], yy[1][b]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int o0, o1, go;
+      uint32_t e0, okm;
+      tile_geom(r, oz, o0, o1, go, e0, okm);
+#pragma unroll
+      for (int o4 = 0; o4 < 4; ++o4) {
+        const bool ok = (okm >> o4) & 1u;
+        float val = yy[o4 >> 1][o4 & 1][r];
+        if (EP == 0) val = val > 0.f ? val : ep.slope * val;
+        if (EP >= 1 && in0c) {
+          val = gv[r * 4 + o4] > 0.f ? val : ep.gate_slope * val;
+          if (EP == 2) {
+            const uint32_t e = e0 + ((o4 >> 1) * ep.dW + (o4 & 1)) * (uint32_t)p.CO0;
+            val = ((kb[r * 4 + o4] >> (e & 7u)) & 1u) ? 2.f * val : 0.f;
+          }
+        }
+        if (!(p.dbg & 1)) {
+          if (ok && in0c) out0n[o0 + (o4 >> 1) * p.o0H + (o4 & 1) * p.o0W] = val;
+          if (EP == 2 && ok && !in0c) out1n[o1 + (o4 >> 1) * p.o1H + (o4 & 1) * p.o1W] = val;
+        }
+      }
+    }
+  };
+
   for (int step = 0; step < nsteps; ++step) {
     const int tz = tz0 + step, oz = 2 * tz + zb, izb = 2 * tz - p.P;
     const bool more = step + 1 < nsteps;
     const int sA = (step & 1) ? 2 : 0;                     // ring slots of the step's input planes 0,1 (2,3 are in the other pair)
     STAMP(0);                                              // barrier B / loop overhead
+    if (late && step > 0) finish(oz - 2);
+    STAMP(2);                                              // deferred epilogue (late waves)
+    if (EP >= 1) fetch_ep(oz);
 
-    // gate values / keep bits of the lane's 16 outputs (4 tiles x 2x2 voxels of plane oz), fetched a whole step ahead of use
-    float gv[16];
-    uint32_t kb[16];
-    if (EP >= 1) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int t = grp * 16 + 4 * q + r;
-        asm volatile("" : "+v"(t));
-        const int ty = (int)fdiv((uint32_t)t, (uint32_t)p.BX, p.magicBX), tx = t - ty * p.BX;
-        const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-        const bool tok = m < CO && t < ntile && in0c && oz < p.OD;
-#pragma unroll
-        for (int o4 = 0; o4 < 4; ++o4) {
-          const int y = oy + (o4 >> 1), x = ox + (o4 & 1);
-          const bool okf = tok && y < p.OH && x < p.OW;
-          gv[r * 4 + o4] = gaten[okf ? oz * ep.gD + y * ep.gH + x * ep.gW + m : 0];
-          if (EP == 2) {
-            const uint32_t e = ((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (y + ep.doy)) * ep.dW + (x + ep.dox)) *
-                                   (uint32_t)p.CO0 + m;
-            kb[r * 4 + o4] = ep.keep_mask[okf ? (e >> 3) : 0];
-          }
-        }
-      }
-    }
-
-    f32x4 acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -260,42 +272,12 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     }
     STAMP(1);                                              // reads + transforms + MFMAs (+ ring hand-over)
 
-    // ---- output transform A^T M A on (y, x); lane = (channel m, tiles 4q .. 4q+3 of the row block: the f32x4 components)
-    f32x4 yx[4][2], yy[2][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) at4(acc[a * 4 + 0], acc[a * 4 + 1], acc[a * 4 + 2], acc[a * 4 + 3], yx[a][0], yx[a][1]);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) at4(yx[0][b], yx[1][b], yx[2][b], yx[3][b], yy[0][b], yy[1][b]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int t = grp * 16 + 4 * q + r;
-      asm volatile("" : "+v"(t));
-      const int ty = (int)fdiv((uint32_t)t, (uint32_t)p.BX, p.magicBX), tx = t - ty * p.BX;
-      const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-      const bool tok = m < CO && t < ntile && oz < p.OD;
-#pragma unroll
-      for (int o4 = 0; o4 < 4; ++o4) {
-        const int y = oy + (o4 >> 1), x = ox + (o4 & 1);
-        const bool ok = tok && y < p.OH && x < p.OW;
-        float val = yy[o4 >> 1][o4 & 1][r];
-        if (EP == 0) val = val > 0.f ? val : ep.slope * val;
-        if (EP >= 1 && in0c) {
-          val = gv[r * 4 + o4] > 0.f ? val : ep.gate_slope * val;
-          if (EP == 2) {
-            const uint32_t e = ((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (y + ep.doy)) * ep.dW + (x + ep.dox)) *
-                                   (uint32_t)p.CO0 + m;
-            val = ((kb[r * 4 + o4] >> (e & 7u)) & 1u) ? 2.f * val : 0.f;
-          }
-        }
-        if (!(p.dbg & 1)) {
-          if (ok && in0c) out0n[oz * p.o0D + y * p.o0H + x * p.o0W + m] = val;
-          if (EP == 2 && ok && !in0c) out1n[oz * p.o1D + y * p.o1H + x * p.o1W + (m - p.CO0)] = val;
-        }
-      }
-    }
-    STAMP(2);                                              // output transform + epilogue
+    if (!late) finish(oz);
+    STAMP(3);                                              // epilogue (early waves)
     __syncthreads();
   }
+  if (late && nsteps > 0) finish(2 * (tz1 - 1) + zb);
+
   if (p.stamps && lane == 0) {
     for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = t_sum[i];
   }
@@ -345,14 +327,6 @@ __global__ __launch_bounds__(256) void wino_weights_k(const float *theta, float 
 constexpr int LDS_MAX = 160 * 1024;
 static thread_local char *g_name = nullptr;
 static thread_local int g_name_len = 0;
-
-static uint32_t magic_for(int d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
-
-static bool fits32(const tem_view &v) {
-  int64_t span = (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH +
-                 (int64_t)(v.W - 1) * v.sW + v.C;
-  return span < (int64_t)1 << 31 && v.sN < ((int64_t)1 << 31);
-}
 
 template <int CI, int CO, int NI>
 int plan(Dev &p, double *cost, size_t *lds_bytes) {

@@ -1,0 +1,422 @@
+// wino_bww.hip -- kernel gradient of the 3x3x3 stride-1 layers with 16 output channels in the Winograd F(2x2, 3x3)
+// domain of the (y, x) axes (the form wino.hip computes the layer in):
+//
+//   Y[z] = sum_kz A^T [ U[kz] (.) V[z + kz] ] A,   U[kz] = G g[kz] G^T,   V = B^T d B
+//   =>  dU[kz]_p (ci, co) = sum_tiles V_p[z + kz][tile][ci] * Z_p[z][tile][co],   Z = A dY A^T   (2x2 -> 4x4)
+//       dg[kz] = G^T dU[kz] G                                                                     (16 points -> 3x3 taps)
+//
+// 48 products per (ci, co) and 2x2 output tile instead of 27 * 4: 2.25x fewer MFMA flops than the direct form.
+//
+// GEMM per Winograd point p: D[(kz, ci)][co] += A[(kz, ci)][4 tiles] * B[4 tiles][co]   (v_mfma_f32_16x16x4_f32, K = tiles).
+//   A operand map: lane = (row = lane & 15, k = lane >> 4) = one ((kz, ci), tile) pair per lane: the lane reads the 4x4 raw
+//   voxels of ITS pair from the LDS image of input plane z + kz and transforms them in registers -- the transformed values
+//   are the A fragments.  B operand map: lane = (co = lane & 15, tile): the lane loads the 2x2 gradient voxels of its
+//   (tile, co) from global memory (64-byte channel runs), expands them to the 4x4 points; Z does not depend on kz, so the
+//   z taps ride in the M dimension (C_in = 16: one 16-row tile per tap; C_in = 8: taps 0,1 share a tile).
+//   All accumulators (taps x 8 points x 4 registers) stay in registers for the whole run of the workgroup.
+//
+// Workgroup = 8 waves: four 16-tile subsets of the block x two halves of the 16 points (rows py 0,1 | 2,3 of the
+// point grid).  Data movement as wino.hip: BY x BX tiles, z march over a ring of 4 input planes filled by LDS-DMA.
+// At the end the four tile subsets are summed through LDS in a fixed order (deterministic), every workgroup writes one
+// Winograd-domain slab; wino_bww_finish_k adds the slabs (fixed order), applies G^T . G and writes the layer's
+// [27][ci][co] gradient as ONE slab of the caller's workspace.
+//
+// Reference call sites: Conv3DBackpropFilter of Conv3D(filters, 3) (models/utils.py:73,122; generator.py:96).
+#include "tem_common.h"
+#include "wino_common.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace wino {
+
+struct BDev {
+  const float *in0, *in1;
+  int32_t i0N, i0D, i0H, i0W, i1N, i1D, i1H, i1W;
+  int32_t C0;
+  int32_t N, D, H, W;
+  const float *dy;
+  int32_t dN, dD, dH, dW;
+  int32_t OD, OH, OW;
+  int32_t P;
+  int32_t BY, BX, nby, nbx, zsegs, zper, NTZ;
+  int32_t E, PLC, subb, slotb, ndma, span0, span1;
+  uint32_t magicBX, magicE;
+  float *wu;                     // Winograd-domain slabs [nblocks][NPART] (NPART = 2 halves x MT tiles x 8 points x 256)
+  int32_t dbg;
+};
+
+template <int CI, int NI>
+__global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
+  constexpr int NH = CI / 8, VB = 32;
+  constexpr int MT = CI == 16 ? 3 : 2;                       // 16-row M tiles: (tap, ci) rows
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char *const ring = reinterpret_cast<char *>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, q = lane >> 4;
+  const int sub = wave >> 1, ph = wave & 1;                  // 16-tile subset of the block; point rows py = 2 ph, 2 ph + 1
+
+  int seg = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int zseg = seg % p.zsegs; seg /= p.zsegs;
+  const int bx = seg % p.nbx; seg /= p.nbx;
+  const int by = seg % p.nby;
+  const int n = seg / p.nby;
+  const int tz0 = zseg * p.zper, tz1 = min(p.NTZ, tz0 + p.zper), nsteps = (p.dbg & 128) ? 0 : tz1 - tz0;
+  const int oy0 = by * 2 * p.BY, ox0 = bx * 2 * p.BX;
+  const int ntile = p.BY * p.BX;
+
+  // ---- LDS-DMA of the input planes (as wino.hip; the sub-images are 64 bytes apart modulo 128 here, see below)
+  const bool two_in = p.in1 != p.in0;
+  const float *const in0n = p.in0 + (size_t)n * p.i0N, *const in1n = p.in1 + (size_t)n * p.i1N;
+  auto dma_plane = [&](int iz, int slot) {
+    const bool zok = (unsigned)iz < (unsigned)p.D;
+    const int izc = zok ? iz : 0;
+    const int iy0 = oy0 - p.P, ix0 = ox0 - p.P;
+    int voff0[NI], voff1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int sp = (wave + 8 * i) * 64 + lane;
+      asm volatile("" : "+v"(sp));
+      const bool ex = sp < p.PLC;
+      const int spc = ex ? sp : 0;
+      const int cpos = spc & 1, ve = spc >> 1;
+      const int ro = (int)fdiv((uint32_t)ve, (uint32_t)p.E, p.magicE), e = ve - ro * p.E;
+      const int o = ro & 1, yr = ro >> 1;
+      const int c = cpos * 4;                                // no chunk swizzle here: see the bank note below
+      const int iy = iy0 + yr, ix = ix0 + 2 * e + o;
+      const bool ok = ex && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      voff0[i] = ok ? (iy * p.i0H + ix * p.i0W + c) * 4 : (int)0x80000000;
+      voff1[i] = ok ? (iy * p.i1H + ix * p.i1W + c) * 4 : (int)0x80000000;
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      char *const dst = ring + slot * p.slotb + h * p.subb;
+      if (!two_in || 8 * h < p.C0)
+        dma_subimage<NI>(in0n + izc * p.i0D + 8 * h, zok ? p.span0 - 32 * h : 0, voff0, dst, wave, p.ndma);
+      else
+        dma_subimage<NI>(in1n + izc * p.i1D + (8 * h - p.C0), zok ? p.span1 - 4 * (8 * h - p.C0) : 0, voff1, dst, wave, p.ndma);
+    }
+  };
+  const int izb0 = 2 * tz0 - p.P;
+  if (nsteps > 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_plane(izb0 + k, k);
+  }
+
+  // ---- per-lane roles.  A: row m = (tap, ci) of M tile mt, tile 4 ks + q of the subset; B: channel m, same tile.
+  // LDS image as wino.hip (8-channel sub-images, rows split into even-x / odd-x voxels) but without the chunk XOR, and
+  // sub-images / ring slots start 32 bytes past a multiple of 128 (subb, slotb = 32 mod 128): a half-wave's read = 16
+  // rows (channels 0..7 | 8..15, or taps 0 | 1 for C_in 8) x the tiles of lane groups q and q + 1 (two tiles = 64 bytes
+  // apart) then covers the 32 banks exactly once.
+  const int ciA = CI == 16 ? m : (m & 7);
+  const int rowb = p.E * VB;
+  // tile pair j of the lane: tiles t0 = 16 sub + 8 j + 2 q (k-step 2 j, the .x of the packed values) and t0 + 1 (k-step
+  // 2 j + 1, .y) -- x neighbours (BX is even): one ds_read2_b32 fetches a raw value of both
+  int abase[2], dybase[2];                                  // byte offset of t0's raw origin inside a plane image; t0's gradient voxel (0,0)
+  uint32_t dyok = 0;                                         // bit 8 j + 4 i + o4: gradient voxel o4 of tile t0 + i exists
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int t = sub * 16 + 8 * j + 2 * q;
+    const int tc = min(t, ntile - 2);
+    const int ty = (int)fdiv((uint32_t)tc, (uint32_t)p.BX, p.magicBX), tx = tc - ty * p.BX;
+    abase[j] = (ciA >> 3) * p.subb + (4 * ty * p.E + tx) * VB + (ciA & 7) * 4;
+    const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+    dybase[j] = oy * p.dH + ox * p.dW + m;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int o4 = 0; o4 < 4; ++o4)
+        dyok |= ((t + i < ntile && oy + (o4 >> 1) < p.OH && ox + 2 * i + (o4 & 1) < p.OW) ? 1u : 0u) << (8 * j + 4 * i + o4);
+  }
+  const float *const dyn = p.dy + (size_t)n * p.dN;
+
+  f32x4 acc[MT][8];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_dy = [&](f32x2 (&g)[2][4], int oz) {             // the lane's 2x2 gradient voxels of its 4 tiles, plane oz
+    const bool zok = oz < p.OD;
+    const float *const base = dyn + (zok ? oz : 0) * p.dD;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int o4 = 0; o4 < 4; ++o4) {
+          const bool ok = zok && ((dyok >> (8 * j + 4 * i + o4)) & 1u);
+          const float v = base[ok ? dybase[j] + (o4 >> 1) * p.dH + (2 * i + (o4 & 1)) * p.dW : 0];
+          if (i) g[j][o4].y = ok ? v : 0.f;
+          else g[j][o4].x = ok ? v : 0.f;
+        }
+  };
+  __syncthreads();
+
+  // The point half ph is wave-uniform; the loop body is compiled once per value (static row indices: no selects).
+  auto run = [&](auto phc) {
+    constexpr int PH = decltype(phc)::value;
+    f32x2 gcur[2][4], gnext[2][4];                           // 2x2 gradient voxels of the lane's tile pairs (k-steps 2 j, 2 j + 1)
+    if (nsteps > 0) load_dy(gcur, 2 * tz0);
+    for (int step = 0; step < nsteps; ++step) {
+      const int tz = tz0 + step, izb = 2 * tz - p.P;
+      const bool more = step + 1 < nsteps;
+      const int sA = (step & 1) ? 2 : 0;
+#pragma unroll
+      for (int zo = 0; zo < 2; ++zo) {
+        // prefetch the gradient voxels of the next output plane (next zo / next step) under this plane's MFMAs
+        if (!(p.dbg & 512)) {
+          if (zo == 0) load_dy(gnext, 2 * tz + 1);
+          else if (more) load_dy(gnext, 2 * tz + 2);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          // input plane of this lane's rows: tap kz = mt (C_in 16) or 2 mt + (m >> 3) (C_in 8; rows 8..15 of tile 1 repeat tap 2)
+          const int kzl = CI == 16 ? mt : min(2, 2 * mt + (m >> 3));
+          const int pl = zo + kzl;
+          const char *plane = ring + ((pl < 2 ? sA : 2 - sA) + (pl & 1)) * p.slotb;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {                        // tile pair: k-steps 2 j (.x) and 2 j + 1 (.y)
+            // raw rows PH .. PH + 2 of the 4x4 tile (the two point rows of this half need three raw rows)
+            f32x2 v[3][4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int dx = 0; dx < 4; ++dx) {
+                const int off = (2 * (PH + i) + (dx & 1)) * rowb + (dx >> 1) * VB;     // row (yr, o) of the image, x half
+                const float *src = reinterpret_cast<const float *>(plane + abase[j] + off);
+                v[i][dx] = (p.dbg & 2) ? f32x2{1.f, 2.f} : f32x2{src[0], src[VB / 4]};  // tiles t0, t0 + 1: one ds_read2_b32
+              }
+            if (zo == 1 && mt == 0 && j == 1) {
+              // every wave is past the step's planes 0 and 1 (zo = 1 starts at plane 1 = its tap 0): they make room for
+              // the next step's planes 2, 3
+              __syncthreads();
+              if (more && !(p.dbg & 4)) { dma_plane(izb + 4, sA); dma_plane(izb + 5, sA + 1); }
+            }
+            // B^T on y for point rows 2 PH, 2 PH + 1, then on x
+            f32x2 vp[2][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              vp[0][c] = PH ? v[1][c] - v[0][c] : v[0][c] - v[2][c];
+              vp[1][c] = PH ? v[0][c] - v[2][c] : v[1][c] + v[2][c];
+            }
+            bt4(vp[0][0], vp[0][1], vp[0][2], vp[0][3]);
+            bt4(vp[1][0], vp[1][1], vp[1][2], vp[1][3]);
+            // Z = A dY A^T for the lane's (co, tile pair), the same two point rows (recomputed per tap: cheaper than
+            // keeping it live)
+            f32x2 zv[2][4];
+            {
+              const f32x2 y00 = gcur[j][0], y01 = gcur[j][1], y10 = gcur[j][2], y11 = gcur[j][3];
+              const f32x2 a0 = PH ? y00 - y10 : y00, b0 = PH ? y01 - y11 : y01;         // point row 2 PH
+              const f32x2 a1 = PH ? -y10 : y00 + y10, b1 = PH ? -y11 : y01 + y11;       // point row 2 PH + 1
+              zv[0][0] = a0; zv[0][1] = a0 + b0; zv[0][2] = a0 - b0; zv[0][3] = -b0;
+              zv[1][0] = a1; zv[1][1] = a1 + b1; zv[1][2] = a1 - b1; zv[1][3] = -b1;
+            }
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt)
+              acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[pt >> 2][pt & 3].x, zv[pt >> 2][pt & 3].x, acc[mt][pt], 0, 0, 0);
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt)
+              acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[pt >> 2][pt & 3].y, zv[pt >> 2][pt & 3].y, acc[mt][pt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);               // one tile pair's raw rows in flight at a time (register budget)
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gcur[jj][i] = gnext[jj][i];
+      }
+      __syncthreads();
+    }
+  };
+  if (ph) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
+
+  // ---- sum the four tile subsets through LDS in a fixed order, one Winograd-domain slab per workgroup:
+  //   part[((ph * MT + mt) * 8 + pt) * 256 + row * 16 + co],  row = 4 q + r
+  float *const part = lds;
+  constexpr int NPART = 2 * MT * 8 * 256;
+  for (int s4 = 0; s4 < ((p.dbg & 64) ? 1 : 4); ++s4) {
+    if (sub == s4) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float *d = part + ((ph * MT + mt) * 8 + pt) * 256 + (4 * q + r) * 16 + m;
+            *d = s4 == 0 ? acc[mt][pt][r] : *d + acc[mt][pt][r];
+          }
+    }
+    __syncthreads();
+  }
+  float *const out = p.wu + (size_t)blockIdx.x * NPART;
+  if (!(p.dbg & 256))
+    for (int i = tid; i < NPART / 4; i += 512) reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(part)[i];
+}
+
+// Sum of the workgroups' slabs (fixed order: four interleaved quarter sums, then their sum) and the inverse kernel
+// transform dg[kz] = G^T dU[kz] G:  slab[((kz*3 + ky)*3 + kx)][ci][co] (+)= sum_{py,px} G[py][ky] G[px][kx] dU[kz][(py,px)][ci][co].
+// One workgroup per (kz, ci): 4 slab quarters x 16 co x 16 points.
+template <int CI>
+__global__ __launch_bounds__(1024) void wino_bww_finish_k(const float *wu, int nslab, float *slab, int accumulate) {
+  constexpr int MT = CI == 16 ? 3 : 2, NPART = 2 * MT * 8 * 256;
+  __shared__ float part[4][16][17], du[16][17];
+  const int tid = threadIdx.x, sg = tid >> 8, pt = (tid >> 4) & 15, co = tid & 15;
+  const int ci = blockIdx.x % CI, kz = blockIdx.x / CI;
+  const int mt = CI == 16 ? kz : (kz >> 1), row = CI == 16 ? ci : ((kz & 1) * 8 + ci);
+  const int py = pt >> 2, px = pt & 3;
+  const int e = (((py >> 1) * MT + mt) * 8 + ((py & 1) * 4 + px)) * 256 + row * 16 + co;
+  float s0 = 0.f, s1 = 0.f;
+  int s = sg;
+  for (; s + 4 < nslab; s += 8) { s0 += wu[(size_t)s * NPART + e]; s1 += wu[(size_t)(s + 4) * NPART + e]; }
+  if (s < nslab) s0 += wu[(size_t)s * NPART + e];
+  part[sg][pt][co] = s0 + s1;
+  __syncthreads();
+  if (sg == 0) du[pt][co] = (part[0][pt][co] + part[1][pt][co]) + (part[2][pt][co] + part[3][pt][co]);
+  __syncthreads();
+  if (tid < 9 * 16) {
+    const int tap = tid >> 4, ky = tap / 3, kx = tap % 3, c = tid & 15;
+    // G^T rows: k = 0: (1, .5, .5, 0); k = 1: (0, .5, -.5, 0); k = 2: (0, .5, .5, 1)
+    const float gy[4] = {ky == 0 ? 1.f : 0.f, 0.5f, ky == 1 ? -0.5f : 0.5f, ky == 2 ? 1.f : 0.f};
+    const float gx[4] = {kx == 0 ? 1.f : 0.f, 0.5f, kx == 1 ? -0.5f : 0.5f, kx == 2 ? 1.f : 0.f};
+    float g = 0.f;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      float r = 0.f;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) r += gx[x] * du[y * 4 + x][c];
+      g += gy[y] * r;
+    }
+    float *d = slab + (size_t)((kz * 3 + ky) * 3 + kx) * CI * 16 + ci * 16 + c;
+    *d = accumulate ? *d + g : g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+constexpr int LDS_MAX_B = 160 * 1024;
+
+template <int CI, int NI>
+static int plan_bww(BDev &p, size_t *lds_bytes) {
+  constexpr int NH = CI / 8, MT = CI == 16 ? 3 : 2;
+  const int TY = (p.OH + 1) / 2, TX = (p.OW + 1) / 2;
+  double best = 1e300;
+  for (int by = 1; by <= TY && by <= 64; ++by)
+    for (int bx = 1; bx <= TX && bx <= 64; ++bx) {
+      const int nt = by * bx;
+      if (nt > 64) continue;
+      const int E = bx + 1, plv = (2 * by + 2) * 2 * E;
+      const int ndma = (plv * 32 + 1023) / 1024;
+      if (bx & 1) continue;                                            // tile pairs (t, t + 1) must not wrap rows
+      const int subb = ndma * 1024 + 32, slotb = ((NH * subb + 127) / 128) * 128 + (NH == 1 ? 32 : 0);
+      const size_t bytes = std::max((size_t)4 * slotb, (size_t)2 * MT * 8 * 256 * 4);
+      if (bytes > (size_t)LDS_MAX_B || ndma > 8 * NI) continue;
+      const int nby = (TY + by - 1) / by, nbx = (TX + bx - 1) / bx;
+      const int cols = p.N * nby * nbx;
+      const double step = 2.0 * 2 * MT * 32 * 45.0 + 4000.0;          // two waves per SIMD, 2 planes x MT x 4 k-steps x 8 MFMAs each
+      const double pro = 8000.0 + 4.0 * slotb / 10.0 + 6000.0;         // prologue + the final LDS reduction and slab write
+      for (int zs = 1; zs <= p.NTZ; ++zs) {
+        const int zper = (p.NTZ + zs - 1) / zs, zsegs = (p.NTZ + zper - 1) / zper;
+        if (zsegs != zs) continue;
+        const double t = std::ceil(cols * zsegs / 256.0) * (pro + zper * step);
+        if (t < best) {
+          best = t; p.BY = by; p.BX = bx; p.nby = nby; p.nbx = nbx; p.zsegs = zsegs; p.zper = zper;
+          p.E = E; p.PLC = plv * 2; p.subb = subb; p.slotb = slotb; p.ndma = ndma; *lds_bytes = (bytes + 15) & ~(size_t)15;
+        }
+      }
+    }
+  return best < 1e300 ? TEM_OK : TEM_EUNSUPPORTED;
+}
+
+// mode 0: launch; 1: workspace query (*ws_floats); 2: describe
+static int run_bww(const tem_bww_args *a, float *ws, hipStream_t st, int mode, int64_t *ws_floats, char *name, int name_len) {
+  const tem_view &i0 = a->in0, &dy = a->dout;
+  const bool cube = a->kd == 3 && a->kh == 3 && a->kw == 3 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->pd == a->ph &&
+                    a->ph == a->pw && a->pd >= 0;
+  if (!cube || i0.D < 2) return TEM_EUNSUPPORTED;
+  if (!fits32(i0) || !fits32(dy)) return TEM_EUNSUPPORTED;
+  BDev p{};
+  p.in0 = i0.ptr; p.i0N = (int)i0.sN; p.i0D = (int)i0.sD; p.i0H = (int)i0.sH; p.i0W = (int)i0.sW; p.C0 = i0.C;
+  p.in1 = i0.ptr; p.i1N = p.i0N; p.i1D = p.i0D; p.i1H = p.i0H; p.i1W = p.i0W;
+  int CI = i0.C;
+  auto aligned = [](const tem_view &v) {
+    return ((uintptr_t)v.ptr & 15) == 0 && v.sW % 4 == 0 && v.sH % 4 == 0 && v.sD % 4 == 0 && v.sN % 4 == 0 && v.C % 4 == 0;
+  };
+  if (!aligned(i0)) return TEM_EUNSUPPORTED;
+  if (a->in1.ptr) {
+    const tem_view &i1 = a->in1;
+    if (i1.N != i0.N || i1.D != i0.D || i1.H != i0.H || i1.W != i0.W) return TEM_ESHAPE;
+    if (!fits32(i1) || !aligned(i1) || i0.C % 8) return TEM_EUNSUPPORTED;
+    p.in1 = i1.ptr; p.i1N = (int)i1.sN; p.i1D = (int)i1.sD; p.i1H = (int)i1.sH; p.i1W = (int)i1.sW;
+    CI += i1.C;
+  }
+  if (dy.C != 16 || (CI != 16 && CI != 8) || dy.N != i0.N) return TEM_EUNSUPPORTED;
+  if (dy.D != i0.D + 2 * a->pd - 2 || dy.H != i0.H + 2 * a->ph - 2 || dy.W != i0.W + 2 * a->pw - 2) return TEM_ESHAPE;
+  p.N = i0.N; p.D = i0.D; p.H = i0.H; p.W = i0.W;
+  p.span0 = (int)(((int64_t)(i0.H - 1) * p.i0H + (int64_t)(i0.W - 1) * p.i0W + i0.C) * 4);
+  p.span1 = a->in1.ptr ? (int)(((int64_t)(i0.H - 1) * p.i1H + (int64_t)(i0.W - 1) * p.i1W + a->in1.C) * 4) : p.span0;
+  p.dy = dy.ptr; p.dN = (int)dy.sN; p.dD = (int)dy.sD; p.dH = (int)dy.sH; p.dW = (int)dy.sW;
+  p.OD = dy.D; p.OH = dy.H; p.OW = dy.W;
+  p.NTZ = (p.OD + 1) / 2;
+  p.P = a->pd;
+  size_t lds_bytes = 0;
+  const int rc = CI == 16 ? plan_bww<16, 2>(p, &lds_bytes) : plan_bww<8, 2>(p, &lds_bytes);
+  if (rc != TEM_OK) return rc;
+  const int MT = CI == 16 ? 3 : 2, npart = 2 * MT * 8 * 256;
+  const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
+  if (mode == 1) { *ws_floats = (int64_t)nblocks * npart; return TEM_OK; }
+  if (mode == 2) { if (name) snprintf(name, name_len, "wino_bww_k<%d, 2>", CI); return TEM_OK; }
+  if (!ws || !a->slabs) return TEM_EINVAL;
+  p.magicBX = magic_for(p.BX); p.magicE = magic_for(p.E);
+  p.wu = ws;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
+    p.dbg = dbg;
+  }
+  if (p.dbg & 8)
+    fprintf(stderr, "wino_bww<%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI,
+            p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
+  static bool attr16 = false, attr8 = false;
+  if (CI == 16) {
+    auto kern = wino_bww_k<16, 2>;
+    if (!attr16) {
+      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_B);
+      if (e != hipSuccess) return (int)e;
+      attr16 = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds_bytes, st, p);
+  } else {
+    auto kern = wino_bww_k<8, 2>;
+    if (!attr8) {
+      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_B);
+      if (e != hipSuccess) return (int)e;
+      attr8 = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds_bytes, st, p);
+  }
+  TEM_CHECK_LAUNCH();
+  if (CI == 16) hipLaunchKernelGGL(wino_bww_finish_k<16>, dim3(3 * 16), dim3(1024), 0, st, ws, nblocks, a->slabs, a->accumulate);
+  else hipLaunchKernelGGL(wino_bww_finish_k<8>, dim3(3 * 8), dim3(1024), 0, st, ws, nblocks, a->slabs, a->accumulate);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+}  // namespace wino
+
+extern "C" int64_t tem_conv_bwd_weight_winograd_ws(const tem_bww_args *a, char *name, int32_t name_len) {
+  if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout)) return TEM_EINVAL;
+  int64_t n = 0;
+  int rc = wino::run_bww(a, nullptr, nullptr, 1, &n, nullptr, 0);
+  if (rc != TEM_OK) return rc;
+  if (name && name_len > 0) wino::run_bww(a, nullptr, nullptr, 2, nullptr, name, name_len);
+  return n;
+}
+
+extern "C" int tem_conv_bwd_weight_winograd(const tem_bww_args *a, float *workspace, tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout)) return TEM_EINVAL;
+  return wino::run_bww(a, workspace, (hipStream_t)stream, 0, nullptr, nullptr, 0);
+}
