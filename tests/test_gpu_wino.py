@@ -9,12 +9,21 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _winograd_for_every_size(monkeypatch):
+    """The product keeps layers under ~30^3 output voxels on the direct form (hip_ops.WINO_MIN_VOXELS); the cases here are
+    small on purpose."""
+    from transfer_em_amd import hip_ops as H
+    monkeypatch.setattr(H, "WINO_MIN_VOXELS", 0)
+
+
 def _oracle_conv(x, w, pad):
     from oracle import ops as O
     return O.conv_fwd(x, w, 1, pad)
 
 
-@pytest.mark.parametrize("ci0,ci1,co,n,slope", [(8, 8, 16, 21, 0.3), (16, 0, 16, 14, 0.3), (8, 0, 16, 17, 0.3), (16, 0, 8, 13, 1.0)])
+@pytest.mark.parametrize("ci0,ci1,co,n,slope", [(8, 8, 16, 21, 0.3), (16, 0, 16, 14, 0.3), (8, 0, 16, 17, 0.3), (16, 0, 8, 13, 1.0),
+                                                 (16, 0, 32, 15, 0.3), (16, 16, 32, 19, 0.3), (32, 0, 32, 11, 0.3)])
 def test_winograd_forward_matches_oracle(ci0, ci1, co, n, slope):
     from transfer_em_amd import hip_ops as H
     from oracle import ops as O
@@ -27,7 +36,7 @@ def test_winograd_forward_matches_oracle(ci0, ci1, co, n, slope):
     dev = "cuda"
     xd = torch.from_numpy(x).to(dev)
     theta = torch.from_numpy(w.reshape(-1)).to(dev)
-    u = torch.zeros((ci // 8) * H.WINO_U_FLOATS, device=dev)
+    u = torch.zeros(H.wino_u_floats(ci, co), device=dev)
     H.run([H.wino_weights_launch("u", theta, u, H.wino_table([(0, 0, ci, co, 0)], dev), 1)])
     out = torch.full((2, n - 2, n - 1, n + 1, co), float("nan"), device=dev)
     l = H.conv_launch("wino", xd[..., :ci0], theta, out, 3, 1, 0, in1=xd[..., ci0:] if ci1 else None, slope=slope, wino=u)
@@ -38,7 +47,8 @@ def test_winograd_forward_matches_oracle(ci0, ci1, co, n, slope):
     assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()) * 3, np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("ci,co0,co1,n,mask", [(16, 8, 8, 12, True), (16, 16, 0, 9, False), (16, 8, 0, 15, False), (8, 16, 0, 10, False)])
+@pytest.mark.parametrize("ci,co0,co1,n,mask", [(16, 8, 8, 12, True), (16, 16, 0, 9, False), (16, 8, 0, 15, False), (8, 16, 0, 10, False),
+                                               (32, 16, 16, 13, True), (16, 32, 0, 11, False), (32, 32, 0, 8, False)])
 def test_winograd_input_gradient_matches_oracle(ci, co0, co1, n, mask):
     """Operator ci -> co0 + co1 = the input-gradient of a (co0 + co1) -> ci layer: pad 2, flipped / transposed kernel, LeakyReLU'
     gate, and (mask) the forward pass's dropout keep bits on out0 with a raw second output."""
@@ -65,7 +75,7 @@ def test_winograd_input_gradient_matches_oracle(ci, co0, co1, n, mask):
         kw = dict(dropout=(7, 3, step), keep_mask=(torch.from_numpy(packed).to(dev), 2))
     gd = torch.from_numpy(g).to(dev)
     theta = torch.from_numpy(w.reshape(-1)).to(dev)
-    u = torch.zeros((ci // 8) * H.WINO_U_FLOATS, device=dev)
+    u = torch.zeros(H.wino_u_floats(ci, co), device=dev)
     H.run([H.wino_weights_launch("u", theta, u, H.wino_table([(0, 0, ci, co, 1)], dev), 1)])
     out = torch.full((1,) + od + (co,), float("nan"), device=dev)
     l = H.conv_launch("wino.bd", gd, theta, out[..., :co0], 3, 1, 2, out1=out[..., co0:] if co1 else None,
@@ -85,7 +95,7 @@ def test_winograd_falls_back_when_unsupported():
     x = torch.randn(1, 9, 9, 9, 32, device=dev)
     theta = torch.randn(27 * 32 * 16, device=dev)
     out = torch.empty(1, 7, 7, 7, 16, device=dev)
-    l = H.conv_launch("c", x, theta, out, 3, 1, 0, slope=0.3, wino=torch.zeros(4 * H.WINO_U_FLOATS, device=dev))   # 32 -> 16: not compiled
+    l = H.conv_launch("c", x, theta, out, 3, 1, 0, slope=0.3, wino=torch.zeros(H.wino_u_floats(32, 16), device=dev))   # 32 -> 16: not compiled
     assert not l.meta["kernel"].startswith("wino_conv_k")
     assert not H.wino_channels(8, 8) and H.wino_channels(16, 16)      # 8 -> 8 stays on the VALU kernel by choice (ParamSet)
     x16 = torch.randn(1, 9, 9, 9, 16, device=dev)

@@ -29,6 +29,12 @@ cases = (
     ("d2a fwd 8->16 62", (8, 0), (16, 0), 62, 0, False, dict(slope=0.3)),
     ("d2a bd 16->8 60 p2", (16, 0), (8, 0), 60, 2, True, dict(gate=True)),
     ("hack fwd 8->16 46", (8, 0), (16, 0), 46, 0, False, dict(slope=0.3)),
+    ("mid fwd 16+16->32 54", (16, 16), (32, 0), 54, 0, False, dict(slope=0.3)),
+    ("mid bd 32->16+16 52 p2", (32, 0), (16, 16), 52, 2, True, dict(gate=True, mask=True)),
+    ("u1a bd 16->32 50 p2", (16, 0), (32, 0), 50, 2, True, dict(gate=True)),
+    ("d.d2a fwd 16->32 44", (16, 0), (32, 0), 44, 0, False, dict(slope=0.3)),
+    ("d3a fwd 32->32 20", (32, 0), (32, 0), 20, 0, False, dict(slope=0.3)),
+    ("d3a bd 32->32 18 p2", (32, 0), (32, 0), 18, 2, True, dict(gate=True)),
 )
 only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
 for name, (ci0, ci1), (co0, co1), nin, pad, flip, kw in cases:
@@ -53,7 +59,7 @@ for name, (ci0, ci1), (co0, co1), nin, pad, flip, kw in cases:
     i0, i1 = views(x, ci0, ci1)
     r0, r1 = views(o_ref, co0, co1)
     w0, w1 = views(o_w, co0, co1)
-    u = torch.zeros((ci // 8) * 6144, device=dev)
+    u = torch.zeros(H.wino_u_floats(ci, co), device=dev)
     # stored kernel: forward layer [tap][ci][co]; input-gradient operator reads the forward layer's [tap][co_op][ci_op] flipped
     tab = H.wino_table([(0, 0, ci, co, 1 if flip else 0)], dev)
     H.run([H.wino_weights_launch("u", theta, u, tab, 1)])

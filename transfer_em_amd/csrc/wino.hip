@@ -65,16 +65,25 @@ struct Dev {
 
 // EP: compiled epilogue -- 0: LeakyReLU(slope) (forward layers); 1: LeakyReLU' gate on the saved activation (input-gradients);
 // 2: gate, the forward pass's dropout keep bits and a second output tensor (input-gradient of a concat through Dropout)
+// C_out = 32: two 16-channel column blocks; the 8 waves are (2 row blocks) x (2 column blocks) x (2 output planes) and a
+// workgroup owns 32 tiles.  C_in = 32 (STREAM): the transformed kernel (196 KB) does not fit beside the ring; it streams
+// through two 32 KB LDS buffers in (z tap, channel-half pair) chunks, one chunk ahead of its use.
 template <int CI, int CO, int NI, int EP>
 __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   constexpr int NH = CI / 8, VB = 32;                        // channel-pair halves = sub-images (8 channels); bytes per sub-image voxel
+  constexpr int NB = (CO + 15) / 16;                         // 16-channel column blocks
+  constexpr bool STREAM = CI == 32;
+  constexpr int UCH = 2 * NB * 16 * 128;                     // floats per streamed chunk: 2 channel halves x NB x 16 points x fragment
+  static_assert(!STREAM || NB == 2, "streamed U: 32 -> 32 only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char *const ring = reinterpret_cast<char *>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, q = lane >> 4;
-  const int grp = wave >> 1, zb = wave & 1;                  // 16-tile row block; output plane of the step
-  const float *const uld = reinterpret_cast<const float *>(ring + 4 * p.slotb);
+  const int grp = NB == 1 ? wave >> 1 : wave >> 2;           // 16-tile row block
+  const int nb = NB == 1 ? 0 : (wave >> 1) & 1, zb = wave & 1;   // column block; output plane of the step
+  const int co = nb * 16 + m;                                // this lane's output channel (C/D column)
+  float *const uld = reinterpret_cast<float *>(ring + 4 * p.slotb);
 
   int seg = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int zseg = seg % p.zsegs; seg /= p.zsegs;
@@ -126,10 +135,21 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) dma_plane(izb0 + k, k);
   }
-  {
-    constexpr int UF4 = 3 * NH * 16 * 64 * 2 / 4;
+  auto dma_u = [&](int chunk, int buf) {                   // streamed kernel chunk (z tap chunk / 2, half pair chunk % 2) -> buffer
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)(p.u + (size_t)chunk * UCH), 0, UCH * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < UCH * 4 / 1024 / 8; ++i) {
+      const int j = wave + 8 * i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)((char *)uld + buf * (UCH * 4) + j * 1024), 16,
+                                               (j * 64 + lane) * 16, 0, 0, 0);
+    }
+  };
+  if (STREAM) {
+    dma_u(0, 0);
+  } else {
+    constexpr int UF4 = 3 * NH * NB * 16 * 64 * 2 / 4;
     const float4 *us = reinterpret_cast<const float4 *>(p.u);
-    float4 *ud = reinterpret_cast<float4 *>(ring + 4 * p.slotb);
+    float4 *ud = reinterpret_cast<float4 *>(uld);
     for (int i = tid; i < UF4; i += 512) ud[i] = us[i];
   }
   __syncthreads();
@@ -138,7 +158,7 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   const Ep32 &ep = p.ep;
   float *const out0n = p.out0 + (size_t)n * p.o0N, *const out1n = EP == 2 ? p.out1 + (size_t)n * p.o1N : nullptr;
   const float *const gaten = EP >= 1 ? ep.gate + (size_t)n * ep.gN : nullptr;
-  const bool in0c = EP != 2 || m < p.CO0;                    // this lane's channel goes to out0 (with the full epilogue)
+  const bool in0c = EP != 2 || co < p.CO0;                   // this lane's channel goes to out0 (with the full epilogue)
 
   // A role: this lane's (tile, channel pair) of the wave's row block
   const int tA = min(grp * 16 + m, ntile - 1);
@@ -165,14 +185,14 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     asm volatile("" : "+v"(t));                              // per-use recompute: nothing per-tile stays in registers
     const int ty = (int)fdiv((uint32_t)t, (uint32_t)p.BX, p.magicBX), tx = t - ty * p.BX;
     const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-    const bool tok = m < CO && t < ntile && oz < p.OD;
+    const bool tok = co < CO && t < ntile && oz < p.OD;
     okm = 0;
 #pragma unroll
     for (int o4 = 0; o4 < 4; ++o4) okm |= ((tok && oy + (o4 >> 1) < p.OH && ox + (o4 & 1) < p.OW) ? 1u : 0u) << o4;
-    o0 = oz * p.o0D + oy * p.o0H + ox * p.o0W + m;
-    o1 = EP == 2 ? oz * p.o1D + oy * p.o1H + ox * p.o1W + (m - p.CO0) : 0;
-    go = EP >= 1 ? oz * ep.gD + oy * ep.gH + ox * ep.gW + m : 0;
-    e0 = EP == 2 ? ((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint32_t)p.CO0 + m : 0u;
+    o0 = oz * p.o0D + oy * p.o0H + ox * p.o0W + co;
+    o1 = EP == 2 ? oz * p.o1D + oy * p.o1H + ox * p.o1W + (co - p.CO0) : 0;
+    go = EP >= 1 ? oz * ep.gD + oy * ep.gH + ox * ep.gW + co : 0;
+    e0 = EP == 2 ? ((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint32_t)p.CO0 + co : 0u;
   };
   auto fetch_ep = [&](int oz) {
 #pragma unroll
@@ -260,7 +280,16 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
         for (int a = 0; a < 4; ++a) bt4(v[a][0], v[a][1], v[a][2], v[a][3]);
 #pragma unroll
         for (int b = 0; b < 4; ++b) bt4(v[0][b], v[1][b], v[2][b], v[3][b]);
-        const float *uh = uld + ((kz * NH + h) * 16) * 128 + lane * 2;
+        if (STREAM && !(h & 1)) {
+          // chunk boundary: every wave is done with the previous chunk's buffer and this chunk has landed (the barrier of
+          // the step's end serves chunk 0); the next chunk -- or the next step's first -- starts flying into the other buffer
+          const int c = kz * 2 + (h >> 1);
+          if (c > 0) __syncthreads();
+          if (c < 5) dma_u(c + 1, (c + 1) & 1);
+          else if (more) dma_u(0, 0);
+        }
+        const float *uh = STREAM ? uld + ((kz * 2 + (h >> 1)) & 1) * UCH + (((h & 1) * NB + nb) * 16) * 128 + lane * 2
+                                 : uld + (((kz * NH + h) * NB + nb) * 16) * 128 + lane * 2;
         f32x2 uf[16];
 #pragma unroll
         for (int pt = 0; pt < 16; ++pt) uf[pt] = *reinterpret_cast<const f32x2 *>(uh + pt * 128);
@@ -286,11 +315,13 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
 
 // ------------------------------------------------------------------------------------------ weights
 // U[kz]_p(ci,co) = sum_{ky,kx} G[py][ky] G[px][kx] w((kz,ky,kx), ci, co), stored in B-fragment order:
-//   u[(((kz*NH + h)*16 + p)*64 + (q*16 + co))*2 + j]  with  ci = 8h + 2q + j, NH = ci/8   (co >= C_out: 0)
+//   u[((((kz*NH + h)*NB + nb)*16 + p)*64 + (q*16 + co % 16))*2 + j]  with  ci = 8h + 2q + j, nb = co / 16,
+//   NH = ci/8, NB = ceil(co/16)   (co >= C_out: 0)
 __global__ __launch_bounds__(256) void wino_weights_k(const float *theta, float *u, const tem_wino_layer *layers) {
   const tem_wino_layer L = layers[blockIdx.x];
-  const int co = threadIdx.x & 15, ci = (threadIdx.x >> 4) + 16 * blockIdx.y;
-  if (ci >= L.ci) return;
+  const int nb = blockIdx.z, NB = (L.co + 15) / 16;
+  const int co = nb * 16 + (threadIdx.x & 15), ci = (threadIdx.x >> 4) + 16 * blockIdx.y;
+  if (ci >= L.ci || nb >= NB) return;
   const int NH = L.ci / 8;
   const int h = ci >> 3, q = (ci & 7) >> 1, j = ci & 1;
   auto g4 = [](float a, float b, float c, float (&o)[4]) {
@@ -317,7 +348,7 @@ __global__ __launch_bounds__(256) void wino_weights_k(const float *theta, float 
 #pragma unroll
       for (int y = 0; y < 4; ++y) gy[y][x] = o[y];
     }
-    float *d = u + L.dst_off + ((int64_t)((kz * NH + h) * 16) * 64 + (q * 16 + co)) * 2 + j;
+    float *d = u + L.dst_off + ((int64_t)(((kz * NH + h) * NB + nb) * 16) * 64 + (q * 16 + (co & 15))) * 2 + j;
 #pragma unroll
     for (int pt = 0; pt < 16; ++pt) d[pt * 128] = gy[pt >> 2][pt & 3];
   }
@@ -330,14 +361,14 @@ static thread_local int g_name_len = 0;
 
 template <int CI, int CO, int NI>
 int plan(Dev &p, double *cost, size_t *lds_bytes) {
-  constexpr int NH = CI / 8;
-  const size_t ubytes = (size_t)3 * NH * 16 * 64 * 2 * 4;
+  constexpr int NH = CI / 8, NB = (CO + 15) / 16;
+  const size_t ubytes = CI == 32 ? (size_t)2 * (2 * NB * 16 * 128) * 4 : (size_t)3 * NH * NB * 16 * 64 * 2 * 4;   // streamed: two chunk buffers
   const int TY = (p.OH + 1) / 2, TX = (p.OW + 1) / 2;
   double best = 1e300;
   for (int by = 1; by <= TY && by <= 64; ++by)
     for (int bx = 1; bx <= TX && bx <= 64; ++bx) {
       const int nt = by * bx;
-      if (nt > 64) continue;
+      if (nt > 64 / NB) continue;
       const int E = bx + 1, plv = (2 * by + 2) * 2 * E;
       const int subb = (plv * 32 + 1023) & ~1023, slotb = NH * subb;
       const size_t bytes = (size_t)4 * slotb + ubytes;
@@ -350,7 +381,7 @@ int plan(Dev &p, double *cost, size_t *lds_bytes) {
       // ONE busy wave (<= 2 row blocks) takes as long, its latencies exposed (measured); a row block that wraps tile
       // rows pays a few LDS bank conflicts; prologue = four planes + U at the CU's HBM share
       const int wraps = (16 % bx) ? 1 : 0;
-      const double step = 2.0 * 3 * NH * 32 * 45.0 * (1.0 + 0.03 * wraps) + 3500.0;
+      const double step = 2.0 * 3 * NH * 32 * 45.0 * (1.0 + 0.03 * wraps) + 3500.0 + (CI == 32 ? 3000.0 : 0.0);
       const double pro = 6000.0 + (4.0 * slotb + ubytes) / 10.0;
       for (int zs = 1; zs <= p.NTZ; ++zs) {
         const int zper = (p.NTZ + zs - 1) / zs, zsegs = (p.NTZ + zper - 1) / zper;
@@ -468,6 +499,8 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   WINO_CASE(8, 8, 2, 0) WINO_CASE(8, 8, 2, 1)
   WINO_CASE(8, 16, 2, 0) WINO_CASE(8, 16, 2, 1)
   WINO_CASE(16, 8, 2, 0) WINO_CASE(16, 8, 2, 1)
+  WINO_CASE(16, 32, 2, 0) WINO_CASE(16, 32, 2, 1)
+  WINO_CASE(32, 32, 2, 0) WINO_CASE(32, 32, 2, 1) WINO_CASE(32, 32, 2, 2)
 #undef WINO_CASE
   return TEM_EUNSUPPORTED;
 }
@@ -487,7 +520,7 @@ extern "C" int tem_winograd_weights(const float *theta, float *u, const tem_wino
                                     tem_stream_t stream) {
   TEM_CLEAR_ERR();
   if (!theta || !u || !layers_dev || nlayers <= 0) return TEM_EINVAL;
-  hipLaunchKernelGGL(wino::wino_weights_k, dim3(nlayers, 2), dim3(256), 0, (hipStream_t)stream, theta, u, layers_dev);
+  hipLaunchKernelGGL(wino::wino_weights_k, dim3(nlayers, 2, 2), dim3(256), 0, (hipStream_t)stream, theta, u, layers_dev);
   TEM_CHECK_LAUNCH();
   return TEM_OK;
 }

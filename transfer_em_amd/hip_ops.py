@@ -129,7 +129,9 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
             ep.keep_mask, ep.keep_mode = mask.data_ptr(), int(mode)
             keep.append(mask)
     bf16 = in0.dtype == torch.bfloat16
-    if wino is not None and not bf16 and not transposed and not direct:
+    # (small layers stay on the direct form: under ~30^3 output voxels the Winograd kernel's prologue outweighs its gain --
+    # measured d.d3a 20^3: 24 us direct, 28 us Winograd)
+    if wino is not None and not bf16 and not transposed and not direct and out0.shape[1] * out0.shape[2] * out0.shape[3] >= WINO_MIN_VOXELS:
         a.w, a.w_layout = wino.data_ptr(), TEM_W_WINOGRAD
         if lib.tem_conv_is_tiled(C.byref(a), 0, None, 0) == 1:
             keep.append(wino)
@@ -401,13 +403,20 @@ def wino_weights_launch(name, theta, u, table_dev, nlayers):
                   [theta, u, table_dev])
 
 
-WINO_U_FLOATS = 6144          # floats of the Winograd-domain copy of one 3x3x3 kernel per 8 input channels (tem_wino_layer)
+WINO_MIN_VOXELS = 27000
+WINO_U_FLOATS = 6144          # floats of the Winograd-domain copy of one 3x3x3 kernel per 8 input and <= 16 output channels
+
+
+def wino_u_floats(ci, co):
+    """Size of the Winograd-domain copy of a ci -> co operator's kernel (tem_wino_layer)."""
+    return (ci // 8) * ((co + 15) // 16) * WINO_U_FLOATS
 
 
 def wino_channels(ci, co):
     """Channel pairs (of the OPERATOR: the input-gradient of a ci -> co layer is a co -> ci operator) that the Winograd
-    kernel is built for and wins on (8 -> 8 stays on the direct VALU kernel: half of every MFMA tile would be empty)."""
-    return (ci, co) in ((16, 16), (8, 16), (16, 8))
+    kernel is built for and wins on (8 -> 8 stays on the direct VALU kernel: half of every MFMA tile would be empty;
+    32 -> 16 has no form that fits the LDS)."""
+    return (ci, co) in ((16, 16), (8, 16), (16, 8), (16, 32), (32, 32))
 
 
 def pack_weights_launch(name, theta, theta_h, theta_ht, table_dev, nlayers):

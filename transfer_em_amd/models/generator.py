@@ -191,11 +191,11 @@ class GenForward:
         L.append(cv("g.d1b", A["d1a"], wf("d1b"), A["d1b"], 4, 2, pc(0, 2, "d1a", "d1b"), slope=H.LEAKY, **kw))
         L.append(cv("g.d2a", A["d1b"], wf("d2a"), A["d2a"], 3, 1, pc(0, 1, "d1b", "d2a"), slope=H.LEAKY, wino=wu("d2a"), **kw))
         L.append(cv("g.d2b", A["d2a"], wf("d2b"), A["d2b"], 4, 2, pc(0, 2, "d2a", "d2b"), slope=H.LEAKY, **kw))
-        L.append(cv("g.u2a", A["d2b"], wf("u2a"), A["u2a"], 3, 1, pc(0, 1, "d2b", "u2a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.u2a", A["d2b"], wf("u2a"), A["u2a"], 3, 1, pc(0, 1, "d2b", "u2a"), slope=H.LEAKY, wino=wu("u2a"), **kw))
         L.append(cv("g.u2b", A["u2a"], wT("u2b"), A["u2b"], 4, 2, pt(1, 2, "u2a", "u2b"), transposed=True,
                     slope=H.LEAKY, dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]), keep_mask=km(0, 1), **kw))
         L.append(cv("g.mid", A["u2b"], wf("mid"), A["mid"], 3, 1, pc(0, 1, "u2b", "mid"), in1=self.skip1,
-                    slope=H.LEAKY, **kw))
+                    slope=H.LEAKY, wino=wu("mid"), **kw))
         L.append(cv("g.u1a", A["mid"], wf("u1a"), A["u1a"], 3, 1, pc(0, 1, "mid", "u1a"), slope=H.LEAKY, **kw))
         L.append(cv("g.u1b", A["u1a"], wT("u1b"), A["u1b"], 4, 2, pt(1, 2, "u1a", "u1b"), transposed=True,
                     slope=H.LEAKY, dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), keep_mask=km(1, 1), **kw))

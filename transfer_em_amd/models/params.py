@@ -48,9 +48,9 @@ class ParamSet:
             if len(s_) == 5 and tuple(s_[:3]) == (3, 3, 3):
                 ci, co = int(s_[3]), int(s_[4])
                 if H.wino_channels(ci, co):
-                    self._u_fwd[k] = off; ents.append((self.offsets[k], off, ci, co, 0)); off += (ci // 8) * H.WINO_U_FLOATS
+                    self._u_fwd[k] = off; ents.append((self.offsets[k], off, ci, co, 0)); off += H.wino_u_floats(ci, co)
                 if H.wino_channels(co, ci):
-                    self._u_bwd[k] = off; ents.append((self.offsets[k], off, co, ci, 1)); off += (co // 8) * H.WINO_U_FLOATS
+                    self._u_bwd[k] = off; ents.append((self.offsets[k], off, co, ci, 1)); off += H.wino_u_floats(co, ci)
         self._u_entries = ents
         self.theta_u = torch.zeros(max(off, 1), dtype=torch.float32, device=self.device)
         self._utable = H.wino_table(ents, self.device) if ents else None
@@ -110,7 +110,8 @@ class ParamSet:
         if o is None:
             return None
         s_ = self.shapes[name]
-        return self.theta_u[o:o + (int(s_[4] if bwd else s_[3]) // 8) * H.WINO_U_FLOATS]
+        ci, co = (int(s_[4]), int(s_[3])) if bwd else (int(s_[3]), int(s_[4]))
+        return self.theta_u[o:o + H.wino_u_floats(ci, co)]
 
     def winograd_launch(self, name="winograd"):
         """Refresh theta_u from theta (None if the network has no Winograd layer)."""
