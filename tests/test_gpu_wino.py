@@ -107,15 +107,16 @@ def test_winograd_falls_back_when_unsupported():
     H.run([l]); torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("ci0,ci1,n,pad", [(8, 8, 13, 0), (16, 0, 10, 0), (8, 0, 11, 0), (16, 0, 9, 2)])
-def test_winograd_kernel_gradient_matches_oracle(ci0, ci1, n, pad):
+@pytest.mark.parametrize("ci0,ci1,n,pad,co", [(8, 8, 13, 0, 16), (16, 0, 10, 0, 16), (8, 0, 11, 0, 16), (16, 0, 9, 2, 16),
+                                              (8, 0, 12, 0, 8), (8, 0, 9, 2, 8)])
+def test_winograd_kernel_gradient_matches_oracle(ci0, ci1, n, pad, co):
     """tem_conv_bwd_weight_winograd (one slab, deterministic) against the oracle's float64 kernel gradient."""
     import ctypes as C
     from transfer_em_amd import hip_ops as H, _lib
     from oracle import ops as O
     H.require_gpu()
     rng = np.random.default_rng(11)
-    ci, co = ci0 + ci1, 16
+    ci = ci0 + ci1
     x = rng.standard_normal((2, n, n + 3, n + 4, ci)).astype(np.float32)
     od = (n + 2 * pad - 2, n + 3 + 2 * pad - 2, n + 4 + 2 * pad - 2)
     g = rng.standard_normal((2,) + od + (co,)).astype(np.float32)

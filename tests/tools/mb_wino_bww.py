@@ -14,7 +14,7 @@ def t(launches, n=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 small = "small" in sys.argv[1:]
-for name, (ci0, ci1), co, nin in (("f1 8+8->16 100", (8, 8), 16, 100), ("d2a 8->16 62", (8, 0), 16, 62), ("hack 8->16 46", (8, 0), 16, 46),
+for name, (ci0, ci1), co, nin in (("d1a 8->8 128", (8, 0), 8, 128), ("d1a cone 8->8 104", (8, 0), 8, 104), ("f1 8+8->16 100", (8, 8), 16, 100), ("d2a 8->16 62", (8, 0), 16, 62), ("hack 8->16 46", (8, 0), 16, 46),
                                   ("f1 cone 8+8->16 64", (8, 8), 16, 64)):
     if small: nin = min(nin, 23)
     ci = ci0 + ci1

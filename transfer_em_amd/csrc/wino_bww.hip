@@ -47,10 +47,17 @@ struct BDev {
   int32_t dbg;
 };
 
-template <int CI, int NI>
+// PAIR (8 -> 8 channels): 8 rows / columns would leave three quarters of every MFMA tile empty.  Instead the rows are
+// (2 input planes x 8 ci) and the columns (2 output planes x 8 co): the four 8x8 blocks of one tile are the products of
+// input plane pl = 2 i + s' (type A) or 2 i + 2 + s' (type B) with output plane zo = 2 i + s, i.e. tap kz = pl - zo:
+//   A: (s',s) = (0,0) kz 0 | (1,0) kz 1 | (1,1) kz 0 | (0,1) kz -1 (unused);   B: (0,0) kz 2 | (0,1) kz 1 | (1,1) kz 2 | (1,0) unused
+// -- every (plane, tap) pair exactly once, three quarters of each tile useful (wino_bww_finish_k adds the blocks up).
+template <int CI, int NI, bool PAIR>
 __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   constexpr int NH = CI / 8, VB = 32;
-  constexpr int MT = CI == 16 ? 3 : 2;                       // 16-row M tiles: (tap, ci) rows
+  constexpr int MT = CI == 16 ? 3 : 2;                       // accumulator tiles per point: (tap, ci) row tiles, or types A / B
+  constexpr int NZO = PAIR ? 1 : 2;                          // output planes handled one after the other per step
+  static_assert(!PAIR || CI == 8, "plane-pair form: 8 -> 8 channels");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char *const ring = reinterpret_cast<char *>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
     const int ty = (int)fdiv((uint32_t)tc, (uint32_t)p.BX, p.magicBX), tx = tc - ty * p.BX;
     abase[j] = (ciA >> 3) * p.subb + (4 * ty * p.E + tx) * VB + (ciA & 7) * 4;
     const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-    dybase[j] = oy * p.dH + ox * p.dW + m;
+    dybase[j] = oy * p.dH + ox * p.dW + (PAIR ? (m & 7) + (m >> 3) * p.dD : m);        // PAIR: column block = output plane
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto load_dy = [&](f32x2 (&g)[2][4], int oz) {             // the lane's 2x2 gradient voxels of its 4 tiles, plane oz
-    const bool zok = oz < p.OD;
+    const bool zok = oz + (PAIR ? (m >> 3) : 0) < p.OD;      // (PAIR: plane oz + column block)
     const float *const base = dyn + (zok ? oz : 0) * p.dD;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -165,17 +172,17 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
       const bool more = step + 1 < nsteps;
       const int sA = (step & 1) ? 2 : 0;
 #pragma unroll
-      for (int zo = 0; zo < 2; ++zo) {
+      for (int zo = 0; zo < NZO; ++zo) {
         // prefetch the gradient voxels of the next output plane (next zo / next step) under this plane's MFMAs
         if (!(p.dbg & 512)) {
-          if (zo == 0) load_dy(gnext, 2 * tz + 1);
+          if (!PAIR && zo == 0) load_dy(gnext, 2 * tz + 1);
           else if (more) load_dy(gnext, 2 * tz + 2);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           // input plane of this lane's rows: tap kz = mt (C_in 16) or 2 mt + (m >> 3) (C_in 8; rows 8..15 of tile 1 repeat tap 2)
           const int kzl = CI == 16 ? mt : min(2, 2 * mt + (m >> 3));
-          const int pl = zo + kzl;
+          const int pl = PAIR ? 2 * mt + (m >> 3) : zo + kzl;  // PAIR: type A rows read planes 0 | 1, type B planes 2 | 3
           const char *plane = ring + ((pl < 2 ? sA : 2 - sA) + (pl & 1)) * p.slotb;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {                        // tile pair: k-steps 2 j (.x) and 2 j + 1 (.y)
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
                 const float *src = reinterpret_cast<const float *>(plane + abase[j] + off);
                 v[i][dx] = (p.dbg & 2) ? f32x2{1.f, 2.f} : f32x2{src[0], src[VB / 4]};  // tiles t0, t0 + 1: one ds_read2_b32
               }
-            if (zo == 1 && mt == 0 && j == 1) {
+            if (PAIR ? (mt == 0 && j == 1) : (zo == 1 && mt == 0 && j == 1)) {
               // every wave is past the step's planes 0 and 1 (zo = 1 starts at plane 1 = its tap 0): they make room for
               // the next step's planes 2, 3
               __syncthreads();
@@ -260,24 +267,35 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
 // Sum of the workgroups' slabs (fixed order: four interleaved quarter sums, then their sum) and the inverse kernel
 // transform dg[kz] = G^T dU[kz] G:  slab[((kz*3 + ky)*3 + kx)][ci][co] (+)= sum_{py,px} G[py][ky] G[px][kx] dU[kz][(py,px)][ci][co].
 // One workgroup per (kz, ci): 4 slab quarters x 16 co x 16 points.
-template <int CI>
+template <int CI, bool PAIR>
 __global__ __launch_bounds__(1024) void wino_bww_finish_k(const float *wu, int nslab, float *slab, int accumulate) {
-  constexpr int MT = CI == 16 ? 3 : 2, NPART = 2 * MT * 8 * 256;
+  constexpr int MT = CI == 16 ? 3 : 2, NPART = 2 * MT * 8 * 256, CO = PAIR ? 8 : 16;
   __shared__ float part[4][16][17], du[16][17];
   const int tid = threadIdx.x, sg = tid >> 8, pt = (tid >> 4) & 15, co = tid & 15;
   const int ci = blockIdx.x % CI, kz = blockIdx.x / CI;
   const int mt = CI == 16 ? kz : (kz >> 1), row = CI == 16 ? ci : ((kz & 1) * 8 + ci);
   const int py = pt >> 2, px = pt & 3;
-  const int e = (((py >> 1) * MT + mt) * 8 + ((py & 1) * 4 + px)) * 256 + row * 16 + co;
+  const int pbase = ((py >> 1) * MT) * 8 + ((py & 1) * 4 + px);          // + 8 * tile: element block of (point, accumulator tile)
+  // the (up to two) 8x8 / 16x16 blocks that make up dU[kz](ci, co) -- PAIR: see wino_bww_k
+  int e0, e1 = -1;
+  if (!PAIR) {
+    e0 = (pbase + 8 * mt) * 256 + row * 16 + co;
+  } else {
+    const int c8 = co & 7;
+    if (kz == 0) { e0 = pbase * 256 + ci * 16 + c8; e1 = pbase * 256 + (8 + ci) * 16 + 8 + c8; }
+    else if (kz == 1) { e0 = pbase * 256 + (8 + ci) * 16 + c8; e1 = (pbase + 8) * 256 + ci * 16 + 8 + c8; }
+    else { e0 = (pbase + 8) * 256 + ci * 16 + c8; e1 = (pbase + 8) * 256 + (8 + ci) * 16 + 8 + c8; }
+  }
   float s0 = 0.f, s1 = 0.f;
-  int s = sg;
-  for (; s + 4 < nslab; s += 8) { s0 += wu[(size_t)s * NPART + e]; s1 += wu[(size_t)(s + 4) * NPART + e]; }
-  if (s < nslab) s0 += wu[(size_t)s * NPART + e];
+  for (int s = sg; s < nslab; s += 4) {
+    s0 += wu[(size_t)s * NPART + e0];
+    if (PAIR) s1 += wu[(size_t)s * NPART + e1];
+  }
   part[sg][pt][co] = s0 + s1;
   __syncthreads();
   if (sg == 0) du[pt][co] = (part[0][pt][co] + part[1][pt][co]) + (part[2][pt][co] + part[3][pt][co]);
   __syncthreads();
-  if (tid < 9 * 16) {
+  if (tid < 9 * 16 && (tid & 15) < CO) {
     const int tap = tid >> 4, ky = tap / 3, kx = tap % 3, c = tid & 15;
     // G^T rows: k = 0: (1, .5, .5, 0); k = 1: (0, .5, -.5, 0); k = 2: (0, .5, .5, 1)
     const float gy[4] = {ky == 0 ? 1.f : 0.f, 0.5f, ky == 1 ? -0.5f : 0.5f, ky == 2 ? 1.f : 0.f};
@@ -290,7 +308,7 @@ __global__ __launch_bounds__(1024) void wino_bww_finish_k(const float *wu, int n
       for (int x = 0; x < 4; ++x) r += gx[x] * du[y * 4 + x][c];
       g += gy[y] * r;
     }
-    float *d = slab + (size_t)((kz * 3 + ky) * 3 + kx) * CI * 16 + ci * 16 + c;
+    float *d = slab + (size_t)((kz * 3 + ky) * 3 + kx) * CI * CO + ci * CO + c;
     *d = accumulate ? *d + g : g;
   }
 }
@@ -352,7 +370,8 @@ static int run_bww(const tem_bww_args *a, float *ws, hipStream_t st, int mode, i
     p.in1 = i1.ptr; p.i1N = (int)i1.sN; p.i1D = (int)i1.sD; p.i1H = (int)i1.sH; p.i1W = (int)i1.sW;
     CI += i1.C;
   }
-  if (dy.C != 16 || (CI != 16 && CI != 8) || dy.N != i0.N) return TEM_EUNSUPPORTED;
+  const bool pair = dy.C == 8 && CI == 8;
+  if (!(pair || (dy.C == 16 && (CI == 16 || CI == 8))) || dy.N != i0.N) return TEM_EUNSUPPORTED;
   if (dy.D != i0.D + 2 * a->pd - 2 || dy.H != i0.H + 2 * a->ph - 2 || dy.W != i0.W + 2 * a->pw - 2) return TEM_ESHAPE;
   p.N = i0.N; p.D = i0.D; p.H = i0.H; p.W = i0.W;
   p.span0 = (int)(((int64_t)(i0.H - 1) * p.i0H + (int64_t)(i0.W - 1) * p.i0W + i0.C) * 4);
@@ -367,7 +386,7 @@ static int run_bww(const tem_bww_args *a, float *ws, hipStream_t st, int mode, i
   const int MT = CI == 16 ? 3 : 2, npart = 2 * MT * 8 * 256;
   const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
   if (mode == 1) { *ws_floats = (int64_t)nblocks * npart; return TEM_OK; }
-  if (mode == 2) { if (name) snprintf(name, name_len, "wino_bww_k<%d, 2>", CI); return TEM_OK; }
+  if (mode == 2) { if (name) snprintf(name, name_len, "wino_bww_k<%d, 2, %s>", CI, pair ? "true" : "false"); return TEM_OK; }
   if (!ws || !a->slabs) return TEM_EINVAL;
   p.magicBX = magic_for(p.BX); p.magicE = magic_for(p.E);
   p.wu = ws;
@@ -379,29 +398,22 @@ static int run_bww(const tem_bww_args *a, float *ws, hipStream_t st, int mode, i
   if (p.dbg & 8)
     fprintf(stderr, "wino_bww<%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI,
             p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
-  static bool attr16 = false, attr8 = false;
-  if (CI == 16) {
-    auto kern = wino_bww_k<16, 2>;
-    if (!attr16) {
+  static bool attr[3] = {false, false, false};
+  auto go = [&](auto kern, auto fin, int nfin, int variant) -> int {
+    if (!attr[variant]) {
       hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_B);
       if (e != hipSuccess) return (int)e;
-      attr16 = true;
+      attr[variant] = true;
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds_bytes, st, p);
-  } else {
-    auto kern = wino_bww_k<8, 2>;
-    if (!attr8) {
-      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_B);
-      if (e != hipSuccess) return (int)e;
-      attr8 = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds_bytes, st, p);
-  }
-  TEM_CHECK_LAUNCH();
-  if (CI == 16) hipLaunchKernelGGL(wino_bww_finish_k<16>, dim3(3 * 16), dim3(1024), 0, st, ws, nblocks, a->slabs, a->accumulate);
-  else hipLaunchKernelGGL(wino_bww_finish_k<8>, dim3(3 * 8), dim3(1024), 0, st, ws, nblocks, a->slabs, a->accumulate);
-  TEM_CHECK_LAUNCH();
-  return TEM_OK;
+    TEM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fin, dim3(nfin), dim3(1024), 0, st, ws, nblocks, a->slabs, a->accumulate);
+    TEM_CHECK_LAUNCH();
+    return TEM_OK;
+  };
+  if (pair) return go(wino_bww_k<8, 2, true>, wino_bww_finish_k<8, true>, 3 * 8, 0);
+  if (CI == 16) return go(wino_bww_k<16, 2, false>, wino_bww_finish_k<16, false>, 3 * 16, 1);
+  return go(wino_bww_k<8, 2, false>, wino_bww_finish_k<8, false>, 3 * 8, 2);
 }
 
 }  // namespace wino

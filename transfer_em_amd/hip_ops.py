@@ -274,9 +274,10 @@ def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=
     a.sd, a.sh, a.sw = _s3(s, is3d)
     a.pd, a.ph, a.pw = _p3(p, is3d)
     namebuf = C.create_string_buffer(96)
-    if wino and not bf16 and is3d and k == 3 and s == 1 and dout.shape[4] == 16 and a.in0.C + (a.in1.C if in1 is not None else 0) == 16:
+    if wino and not bf16 and is3d and k == 3 and s == 1 and \
+            (a.in0.C + (a.in1.C if in1 is not None else 0), dout.shape[4]) in ((16, 16), (8, 8)):
         # Winograd-domain kernel gradient (one slab, own scratch).  The library also has C_in 8 -> C_out 16; measured
-        # no faster than the direct form there (g.d2a 36.7 vs 39.2 us, d.hack 26.7 vs 26.8), so only 16 -> 16 takes it.
+        # no faster than the direct form there (g.d2a 36.7 vs 39.2 us, d.hack 26.7 vs 26.8): 16 -> 16 and 8 -> 8 take it.
         nws = lib.tem_conv_bwd_weight_winograd_ws(C.byref(a), namebuf, 96)
         if nws > 0:
             scratch = torch.empty(int(nws), dtype=torch.float32, device=in0.device)
