@@ -290,7 +290,8 @@ int tem_flip_transpose(const float *theta, float *theta_t, const tem_wlayer *lay
 /* One kernel of tem_winograd_weights: the 27 taps of a [ci][co] block at theta + src_off (flip = 0: the operator's
  * kernel is theta[tap][ci][co], a forward Conv layer; flip = 1: theta[26-tap][co][ci], its input-gradient) are
  * transformed to U[kz] = G g[kz] G^T on the (y, x) axes (16 points per z tap) and written at u + dst_off in the fragment
- * order of the Winograd kernel: (ci / 8) * 6144 floats per layer (ci, co <= 16 here: the operator's channel counts). */
+ * order of the Winograd kernel: (ci / 8) * ceil(co / 16) * 6144 floats per layer (8 -> 8: 8192), ci, co the operator's
+ * channel counts (8, 16 or 32; 32 -> 16 is not built). */
 typedef struct tem_wino_layer {
   int64_t src_off, dst_off;
   int32_t ci, co, flip;

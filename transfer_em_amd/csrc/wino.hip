@@ -73,6 +73,12 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   constexpr int NH = CI / 8, VB = 32;                        // channel-pair halves = sub-images (8 channels); bytes per sub-image voxel
   constexpr int NB = (CO + 15) / 16;                         // 16-channel column blocks
   constexpr bool STREAM = CI == 32;
+  // PAIR (8 -> 8 channels): the 16 columns of a tile are (2 output planes x 8 co) -- input plane pl of the step multiplies
+  // with the kernel taps kz = pl - s of both output planes s at once (a zero block where kz leaves 0..2; fragment layout
+  // of tem_winograd_weights for 8 -> 8), 4 MFMA passes per k-step for two planes instead of 6 half-empty ones; every
+  // wave owns a 16-tile row block and both planes, a workgroup 128 tiles.
+  constexpr bool PAIR = CI == 8 && CO == 8;
+  constexpr int NKZ = PAIR ? 4 : 3;                          // z passes per step
   constexpr int UCH = 2 * NB * 16 * 128;                     // floats per streamed chunk: 2 channel halves x NB x 16 points x fragment
   static_assert(!STREAM || NB == 2, "streamed U: 32 -> 32 only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -80,9 +86,10 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, q = lane >> 4;
-  const int grp = NB == 1 ? wave >> 1 : wave >> 2;           // 16-tile row block
-  const int nb = NB == 1 ? 0 : (wave >> 1) & 1, zb = wave & 1;   // column block; output plane of the step
-  const int co = nb * 16 + m;                                // this lane's output channel (C/D column)
+  const int grp = PAIR ? wave : (NB == 1 ? wave >> 1 : wave >> 2);   // 16-tile row block
+  const int nb = NB == 1 ? 0 : (wave >> 1) & 1;              // column block
+  const int zb = PAIR ? (m >> 3) : (wave & 1);               // output plane of the step: per wave, or (PAIR) per column half
+  const int co = PAIR ? (m & 7) : nb * 16 + m;               // this lane's output channel (C/D column)
   float *const uld = reinterpret_cast<float *>(ring + 4 * p.slotb);
 
   int seg = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   if (STREAM) {
     dma_u(0, 0);
   } else {
-    constexpr int UF4 = 3 * NH * NB * 16 * 64 * 2 / 4;
+    constexpr int UF4 = NKZ * NH * NB * 16 * 64 * 2 / 4;
     const float4 *us = reinterpret_cast<const float4 *>(p.u);
     float4 *ud = reinterpret_cast<float4 *>(uld);
     for (int i = tid; i < UF4; i += 512) ud[i] = us[i];
@@ -257,9 +264,9 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-      // input plane zb + kz of the step: planes 0,1 live in slots sA, sA+1, planes 2,3 in the other pair
-      const int pl = zb + kz;
+    for (int kz = 0; kz < NKZ; ++kz) {
+      // input plane zb + kz of the step (PAIR: plane kz): planes 0,1 live in slots sA, sA+1, planes 2,3 in the other pair
+      const int pl = PAIR ? kz : zb + kz;
       const char *plane = ring + ((pl < 2 ? sA : 2 - sA) + (pl & 1)) * p.slotb + a0;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -306,6 +313,7 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     __syncthreads();
   }
   if (late && nsteps > 0) finish(2 * (tz1 - 1) + zb);
+  static_assert(!PAIR || EP <= 1, "8 -> 8: forward and gated input-gradient only");
 
   if (p.stamps && lane == 0) {
     for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = t_sum[i];
@@ -323,7 +331,37 @@ __global__ __launch_bounds__(256) void wino_weights_k(const float *theta, float 
   const int co = nb * 16 + (threadIdx.x & 15), ci = (threadIdx.x >> 4) + 16 * blockIdx.y;
   if (ci >= L.ci || nb >= NB) return;
   const int NH = L.ci / 8;
+  const bool pair = L.ci == 8 && L.co == 8;                  // 8 -> 8: columns = (output plane s, co), one fragment set per input plane
   const int h = ci >> 3, q = (ci & 7) >> 1, j = ci & 1;
+  if (pair) {
+    if (nb) return;
+    const int c16 = threadIdx.x & 15, s_ = c16 >> 3, c8 = c16 & 7;
+    auto g4p = [](float a, float b, float c, float (&o)[4]) {
+      o[0] = a; o[1] = 0.5f * (a + b + c); o[2] = 0.5f * (a - b + c); o[3] = c;
+    };
+    for (int pl = 0; pl < 4; ++pl) {
+      const int kz = pl - s_;
+      float gy[4][4];
+      if (kz >= 0 && kz <= 2) {
+        float g[3][3], gx[3][4];
+        for (int t9 = 0; t9 < 9; ++t9) {
+          const int t = kz * 9 + t9;
+          g[t9 / 3][t9 % 3] = L.flip ? theta[L.src_off + ((int64_t)(26 - t) * 8 + c8) * 8 + ci] : theta[L.src_off + ((int64_t)t * 8 + ci) * 8 + c8];
+        }
+        for (int a = 0; a < 3; ++a) g4p(g[a][0], g[a][1], g[a][2], gx[a]);
+        for (int x = 0; x < 4; ++x) {
+          float o[4];
+          g4p(gx[0][x], gx[1][x], gx[2][x], o);
+          for (int y = 0; y < 4; ++y) gy[y][x] = o[y];
+        }
+      } else {
+        for (int y = 0; y < 4; ++y) for (int x = 0; x < 4; ++x) gy[y][x] = 0.f;
+      }
+      float *d = u + L.dst_off + ((int64_t)(pl * 16) * 64 + (q * 16 + c16)) * 2 + j;
+      for (int pt = 0; pt < 16; ++pt) d[pt * 128] = gy[pt >> 2][pt & 3];
+    }
+    return;
+  }
   auto g4 = [](float a, float b, float c, float (&o)[4]) {
     o[0] = a; o[1] = 0.5f * (a + b + c); o[2] = 0.5f * (a - b + c); o[3] = c;
   };
@@ -362,13 +400,15 @@ static thread_local int g_name_len = 0;
 template <int CI, int CO, int NI>
 int plan(Dev &p, double *cost, size_t *lds_bytes) {
   constexpr int NH = CI / 8, NB = (CO + 15) / 16;
-  const size_t ubytes = CI == 32 ? (size_t)2 * (2 * NB * 16 * 128) * 4 : (size_t)3 * NH * NB * 16 * 64 * 2 * 4;   // streamed: two chunk buffers
+  constexpr bool PAIR = CI == 8 && CO == 8;
+  const size_t ubytes = CI == 32 ? (size_t)2 * (2 * NB * 16 * 128) * 4                       // streamed: two chunk buffers
+                                 : (size_t)(PAIR ? 4 : 3) * NH * NB * 16 * 64 * 2 * 4;
   const int TY = (p.OH + 1) / 2, TX = (p.OW + 1) / 2;
   double best = 1e300;
   for (int by = 1; by <= TY && by <= 64; ++by)
     for (int bx = 1; bx <= TX && bx <= 64; ++bx) {
       const int nt = by * bx;
-      if (nt > 64 / NB) continue;
+      if (nt > (PAIR ? 128 : 64 / NB)) continue;
       const int E = bx + 1, plv = (2 * by + 2) * 2 * E;
       const int subb = (plv * 32 + 1023) & ~1023, slotb = NH * subb;
       const size_t bytes = (size_t)4 * slotb + ubytes;
@@ -381,7 +421,7 @@ int plan(Dev &p, double *cost, size_t *lds_bytes) {
       // ONE busy wave (<= 2 row blocks) takes as long, its latencies exposed (measured); a row block that wraps tile
       // rows pays a few LDS bank conflicts; prologue = four planes + U at the CU's HBM share
       const int wraps = (16 % bx) ? 1 : 0;
-      const double step = 2.0 * 3 * NH * 32 * 45.0 * (1.0 + 0.03 * wraps) + 3500.0 + (CI == 32 ? 3000.0 : 0.0);
+      const double step = 2.0 * (PAIR ? 4 : 3) * NH * 32 * 45.0 * (1.0 + 0.03 * wraps) + 3500.0 + (CI == 32 ? 3000.0 : 0.0);
       const double pro = 6000.0 + (4.0 * slotb + ubytes) / 10.0;
       for (int zs = 1; zs <= p.NTZ; ++zs) {
         const int zper = (p.NTZ + zs - 1) / zs, zsegs = (p.NTZ + zper - 1) / zper;
@@ -496,7 +536,7 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   }
 #define WINO_CASE(ci, co, ni, epi) if (CI == ci && CO == co && EP == epi) return run_best<ci, co, ni, epi>(p, st, dry);
   WINO_CASE(16, 16, 2, 0) WINO_CASE(16, 16, 2, 1) WINO_CASE(16, 16, 2, 2)
-  WINO_CASE(8, 8, 2, 0) WINO_CASE(8, 8, 2, 1)
+  WINO_CASE(8, 8, 3, 0) WINO_CASE(8, 8, 3, 1)
   WINO_CASE(8, 16, 2, 0) WINO_CASE(8, 16, 2, 1)
   WINO_CASE(16, 8, 2, 0) WINO_CASE(16, 8, 2, 1)
   WINO_CASE(16, 32, 2, 0) WINO_CASE(16, 32, 2, 1)

@@ -410,14 +410,15 @@ WINO_U_FLOATS = 6144          # floats of the Winograd-domain copy of one 3x3x3 
 
 def wino_u_floats(ci, co):
     """Size of the Winograd-domain copy of a ci -> co operator's kernel (tem_wino_layer)."""
+    if (ci, co) == (8, 8):
+        return 8192                 # plane-pair fragments: one set per input plane of a step (4 x 16 points x 128)
     return (ci // 8) * ((co + 15) // 16) * WINO_U_FLOATS
 
 
 def wino_channels(ci, co):
     """Channel pairs (of the OPERATOR: the input-gradient of a ci -> co layer is a co -> ci operator) that the Winograd
-    kernel is built for and wins on (8 -> 8 stays on the direct VALU kernel: half of every MFMA tile would be empty;
-    32 -> 16 has no form that fits the LDS)."""
-    return (ci, co) in ((16, 16), (8, 16), (16, 8), (16, 32), (32, 32))
+    kernel is built for and wins on (32 -> 16 has no form that fits the LDS)."""
+    return (ci, co) in ((8, 8), (16, 16), (8, 16), (16, 8), (16, 32), (32, 32))
 
 
 def pack_weights_launch(name, theta, theta_h, theta_ht, table_dev, nlayers):

@@ -187,7 +187,7 @@ class GenForward:
         wu = (lambda name: None) if (bf or direct) else P.u
         cv = H.conv_launch
         L.append(cv("g.c0", x, wf("c0"), A["c0"], 3, 1, pc(in_pad, 1, "", "c0"), slope=H.LEAKY, **kw))
-        L.append(cv("g.d1a", A["c0"], wf("d1a"), A["d1a"], 3, 1, pc(0, 1, "c0", "d1a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.d1a", A["c0"], wf("d1a"), A["d1a"], 3, 1, pc(0, 1, "c0", "d1a"), slope=H.LEAKY, wino=wu("d1a"), **kw))
         L.append(cv("g.d1b", A["d1a"], wf("d1b"), A["d1b"], 4, 2, pc(0, 2, "d1a", "d1b"), slope=H.LEAKY, **kw))
         L.append(cv("g.d2a", A["d1b"], wf("d2a"), A["d2a"], 3, 1, pc(0, 1, "d1b", "d2a"), slope=H.LEAKY, wino=wu("d2a"), **kw))
         L.append(cv("g.d2b", A["d2a"], wf("d2b"), A["d2b"], 4, 2, pc(0, 2, "d2a", "d2b"), slope=H.LEAKY, **kw))
