@@ -150,3 +150,20 @@ def test_warp_tensor_blur_and_holes():
     z = warp_tensor(x, OneHole())[..., 0]
     mean = np.float32(9.0 / 81)
     assert np.allclose(z[2:6, 2:6], mean) and z[1, 4] == 0.0 and z[6, 6] == 0.0      # SAME, k=4: the hole at 4 marks outputs 3..6 - 1 = 2..5
+
+
+def test_paramset_winograd_tables():
+    """ParamSet lists a Winograd-domain copy for exactly the 3x3x3 kernels whose forward / input-gradient operator has a
+    Winograd form (hip_ops.wino_channels), with non-overlapping slices of theta_u."""
+    from transfer_em_amd import hip_ops as H
+    from transfer_em_amd.models.generator import generator_param_shapes
+    from transfer_em_amd.models.params import ParamSet
+    P = ParamSet(generator_param_shapes(True, 8), "cpu", seed=0)
+    assert set(P._u_fwd) == {"d1a", "d2a", "u2a", "mid", "f1"}              # 8->8, 8->16, 16->32, 32->32, 16->16
+    assert set(P._u_bwd) == {"d1a", "d2a", "mid", "u1a", "f1"}              # operators 8->8, 16->8, 32->32, 16->32, 16->16 (u2a's 32->16: none)
+    spans = sorted((e[1], e[1] + H.wino_u_floats(e[2], e[3])) for e in P._u_entries)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] == P.theta_u.numel()
+    assert P.u("c0") is None and P.u("u1a") is None and P.u("u1a", bwd=True).numel() == H.wino_u_floats(16, 32)
+    assert H.wino_u_floats(8, 8) == 8192 and H.wino_u_floats(32, 32) == 4 * 2 * H.WINO_U_FLOATS
+    P2 = ParamSet(generator_param_shapes(False, 8), "cpu", seed=0)          # 2-D networks: no Winograd layer
+    assert P2._utable is None and P2.winograd_launch() is None
