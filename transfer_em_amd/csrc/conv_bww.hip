@@ -201,10 +201,12 @@ int launch_bww(const BwwDev &p, hipStream_t st) {
 }  // namespace
 
 int tem_bww_lds_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out);   // bww_lds.hip
+int tem_bww_c1_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out);    // bww_c1.hip (C_in = 1 layers)
 
 extern "C" int tem_conv_bwd_weight_nslab(const tem_bww_args *a) {
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout) || a->nslab < 1) return TEM_EINVAL;
   int n = 0;
+  if (tem_bww_c1_try(a, nullptr, true, &n) == TEM_OK) return n;
   if (tem_bww_lds_try(a, nullptr, true, &n) == TEM_OK) return n;
   return a->nslab < 32 ? a->nslab : 32;          // global-load kernel: any split works, 32 is plenty
 }
@@ -217,6 +219,11 @@ extern "C" int tem_conv_bwd_weight(const tem_bww_args *a, tem_stream_t stream) {
     // the tiled kernel writes exactly tem_conv_bwd_weight_nslab(a) slabs; take it only when the
     // caller sized the workspace with that query (nslab equal), otherwise slabs would be left stale
     int n = 0;
+    {
+      // (the C_in = 1 kernel sizes its z runs by the slab budget: ask with the caller's own count as the budget)
+      if (tem_bww_c1_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab)
+        return tem_bww_c1_try(a, (hipStream_t)stream, false, nullptr);
+    }
     if (tem_bww_lds_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab)
       return tem_bww_lds_try(a, (hipStream_t)stream, false, nullptr);
   }
