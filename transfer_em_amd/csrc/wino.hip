@@ -186,16 +186,24 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   f32x4 acc[16];
   float gv[16];                                            // gate values / keep-bit bytes of the lane's 16 outputs
   uint32_t kb[16];                                         //   (4 tiles x 2x2 voxels of one plane), fetched a step ahead of use
-  // per tile r of the lane: offsets of its voxel (0, 0) in the output / gate / dropout frames and a validity mask
-  auto tile_geom = [&](int r, int oz, int &o0, int &o1, int &go, uint32_t &e0, uint32_t &okm) {
-    int t = grp * 16 + 4 * q + r;
-    asm volatile("" : "+v"(t));                              // per-use recompute: nothing per-tile stays in registers
+  // per tile r of the lane (tiles 4q .. 4q+3 of the row block): its output voxel (0, 0) as (oy << 16 | ox) and the validity
+  // of its 2x2 voxels -- computed once (the tiles do not move along z); offsets are a few multiply-adds from these
+  uint32_t tyx[4], tok4 = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = grp * 16 + 4 * q + r;
     const int ty = (int)fdiv((uint32_t)t, (uint32_t)p.BX, p.magicBX), tx = t - ty * p.BX;
     const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-    const bool tok = co < CO && t < ntile && oz < p.OD;
-    okm = 0;
+    const bool tok = co < CO && t < ntile;
 #pragma unroll
-    for (int o4 = 0; o4 < 4; ++o4) okm |= ((tok && oy + (o4 >> 1) < p.OH && ox + (o4 & 1) < p.OW) ? 1u : 0u) << o4;
+    for (int o4 = 0; o4 < 4; ++o4) tok4 |= ((tok && oy + (o4 >> 1) < p.OH && ox + (o4 & 1) < p.OW) ? 1u : 0u) << (4 * r + o4);
+    tyx[r] = ((uint32_t)oy << 16) | (uint32_t)ox;
+  }
+  auto tile_geom = [&](int r, int oz, int &o0, int &o1, int &go, uint32_t &e0, uint32_t &okm) {
+    uint32_t yx = tyx[r];
+    asm volatile("" : "+v"(yx));                             // per-use recompute: no per-output offsets hoisted out of the step loop
+    const int oy = (int)(yx >> 16), ox = (int)(yx & 0xffffu);
+    okm = oz < p.OD ? (tok4 >> (4 * r)) & 15u : 0u;
     o0 = oz * p.o0D + oy * p.o0H + ox * p.o0W + co;
     o1 = EP == 2 ? oz * p.o1D + oy * p.o1H + ox * p.o1W + (co - p.CO0) : 0;
     go = EP >= 1 ? oz * ep.gD + oy * ep.gH + ox * ep.gW + co : 0;
