@@ -303,13 +303,14 @@ typedef struct tem_wino_layer {
 int tem_winograd_weights(const float *theta, float *u, const tem_wino_layer *layers_dev, int32_t nlayers,
                          tem_stream_t stream);
 
-/* Kernel gradient of a k 3, s 1 layer with 16 output channels and 8 or 16 input channels in the Winograd domain of
- * tem_winograd_weights (2.25x fewer matrix flops than tem_conv_bwd_weight; same operator, fp32 rounding differs).  The
- * result is written as ONE slab at a->slabs (a->nslab is ignored, a->accumulate honoured); the partial sums are
- * deterministic (fixed summation order).  `workspace`: tem_conv_bwd_weight_winograd_ws(a) floats of scratch
- * (negative: TEM_E*, e.g. TEM_EUNSUPPORTED for other geometries; `name`, if non-NULL, receives the kernel's name). */
-int64_t tem_conv_bwd_weight_winograd_ws(const tem_bww_args *a, char *name, int32_t name_len);
-int tem_conv_bwd_weight_winograd(const tem_bww_args *a, float *workspace, tem_stream_t stream);
+/* Kernel gradient of a k 3, s 1 layer (C_in -> C_out: 16 -> 16, 8 -> 16, 8 -> 8) in the Winograd domain of
+ * tem_winograd_weights (2.25x fewer matrix flops than tem_conv_bwd_weight; same operator, fp32 rounding differs).  Same
+ * slab contract as tem_conv_bwd_weight: the launch writes exactly tem_conv_bwd_weight_winograd_nslab(a) slabs (query
+ * with a->nslab = the caller's upper bound; negative: TEM_E*, e.g. TEM_EUNSUPPORTED for other geometries; `name`, if
+ * non-NULL, receives the kernel's name), one per workgroup, already transformed back to [27][ci][co]; pass that value
+ * as a->nslab.  Deterministic (fixed summation orders). */
+int tem_conv_bwd_weight_winograd_nslab(const tem_bww_args *a, char *name, int32_t name_len);
+int tem_conv_bwd_weight_winograd(const tem_bww_args *a, tem_stream_t stream);
 
 /* g(view) = saved(view) > 0 ? g : slope * g, in place: LeakyReLU gradient gated on the saved output where no
  * convolution epilogue can carry it (gradient entering the frozen prior network, discriminator.py:62-66). */

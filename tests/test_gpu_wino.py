@@ -110,7 +110,7 @@ def test_winograd_falls_back_when_unsupported():
 @pytest.mark.parametrize("ci0,ci1,n,pad,co", [(8, 8, 13, 0, 16), (16, 0, 10, 0, 16), (8, 0, 11, 0, 16), (16, 0, 9, 2, 16),
                                               (8, 0, 12, 0, 8), (8, 0, 9, 2, 8)])
 def test_winograd_kernel_gradient_matches_oracle(ci0, ci1, n, pad, co):
-    """tem_conv_bwd_weight_winograd (one slab, deterministic) against the oracle's float64 kernel gradient."""
+    """tem_conv_bwd_weight_winograd (one slab per workgroup, deterministic) against the oracle's float64 kernel gradient."""
     import ctypes as C
     from transfer_em_amd import hip_ops as H, _lib
     from oracle import ops as O
@@ -131,17 +131,17 @@ def test_winograd_kernel_gradient_matches_oracle(ci0, ci1, n, pad, co):
     a.dout = H.view(gd)
     a.kd = a.kh = a.kw = 3; a.sd = a.sh = a.sw = 1; a.pd = a.ph = a.pw = pad
     name = C.create_string_buffer(64)
-    nws = lib.tem_conv_bwd_weight_winograd_ws(C.byref(a), name, 64)
-    assert nws > 0 and name.value.decode().startswith("wino_bww_k"), (nws, name.value)
-    scratch = torch.empty(int(nws), device=dev)
+    a.nslab = 1024
+    nsl = lib.tem_conv_bwd_weight_winograd_nslab(C.byref(a), name, 64)
+    assert nsl > 0 and name.value.decode().startswith("wino_bww_k"), (nsl, name.value)
     outs = []
     for _ in range(2):                                                   # twice: the sums are order-deterministic
-        slab = torch.full((27 * ci * co,), float("nan"), device=dev)
-        a.slabs, a.nslab, a.accumulate = slab.data_ptr(), 1, 0
-        rc = lib.tem_conv_bwd_weight_winograd(C.byref(a), scratch.data_ptr(), H.current_stream())
+        slabs = torch.full((nsl, 27 * ci * co), float("nan"), device=dev)
+        a.slabs, a.nslab, a.accumulate = slabs.data_ptr(), nsl, 0
+        rc = lib.tem_conv_bwd_weight_winograd(C.byref(a), H.current_stream())
         assert rc == 0
         torch.cuda.synchronize()
-        outs.append(slab.cpu().numpy().reshape(3, 3, 3, ci, co))
+        outs.append(slabs.double().sum(0).cpu().numpy().reshape(3, 3, 3, ci, co))
     assert np.array_equal(outs[0], outs[1])
     err = np.abs(outs[0] - ref).max()
     assert err <= 3e-6 * np.abs(ref).max() + 1e-4, (err, np.abs(ref).max())

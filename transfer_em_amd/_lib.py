@@ -112,8 +112,8 @@ _SIGS = {
     "tem_add_view": [_VP, _VP, C.c_void_p],
     "tem_leaky_gate_view": [_VP, _VP, C.c_float, C.c_void_p],
     "tem_flip_transpose": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p],
-    "tem_conv_bwd_weight_winograd_ws": [C.POINTER(tem_bww_args), C.c_char_p, C.c_int32],
-    "tem_conv_bwd_weight_winograd": [C.POINTER(tem_bww_args), C.c_void_p, C.c_void_p],
+    "tem_conv_bwd_weight_winograd_nslab": [C.POINTER(tem_bww_args), C.c_char_p, C.c_int32],
+    "tem_conv_bwd_weight_winograd": [C.POINTER(tem_bww_args), C.c_void_p],
     "tem_winograd_weights": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
     "tem_instance_norm": [_VP, C.c_void_p, C.c_void_p, C.c_float, _VP, C.c_void_p, C.c_void_p, C.c_void_p],
     "tem_instance_norm_bwd": [_VP, _VP, C.c_void_p, C.c_void_p, C.c_void_p, _VP, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -141,7 +141,7 @@ def load():
         except AttributeError as e:
             raise TemError(f"libtem_hip.so does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name == "tem_conv_bwd_weight_winograd_ws" else C.c_int
+        fn.restype = C.c_int
     _lib = lib
     return lib
 

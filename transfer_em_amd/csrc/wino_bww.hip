@@ -17,9 +17,9 @@
 //
 // Workgroup = 8 waves: four 16-tile subsets of the block x two halves of the 16 points (rows py 0,1 | 2,3 of the
 // point grid).  Data movement as wino.hip: BY x BX tiles, z march over a ring of 4 input planes filled by LDS-DMA.
-// At the end the four tile subsets are summed through LDS in a fixed order (deterministic), every workgroup writes one
-// Winograd-domain slab; wino_bww_finish_k adds the slabs (fixed order), applies G^T . G and writes the layer's
-// [27][ci][co] gradient as ONE slab of the caller's workspace.
+// At the end the four tile subsets are summed through LDS in a fixed order (deterministic) and the workgroup applies
+// G^T . G to its partial sums itself: what it writes is an ordinary [27][ci][co] slab, summed over the workgroups by
+// tem_reduce_slabs_multi like the slabs of the direct-form kernel.
 //
 // Reference call sites: Conv3DBackpropFilter of Conv3D(filters, 3) (models/utils.py:73,122; generator.py:96).
 #include "tem_common.h"
@@ -43,7 +43,7 @@ struct BDev {
   int32_t BY, BX, nby, nbx, zsegs, zper, NTZ;
   int32_t E, PLC, subb, slotb, ndma, span0, span1;
   uint32_t magicBX, magicE;
-  float *wu;                     // Winograd-domain slabs [nblocks][NPART] (NPART = 2 halves x MT tiles x 8 points x 256)
+  float *slabs; int64_t slab_stride;   // one kernel-gradient slab [27][ci][co] per workgroup
   int32_t dbg;
 };
 
@@ -51,7 +51,7 @@ struct BDev {
 // (2 input planes x 8 ci) and the columns (2 output planes x 8 co): the four 8x8 blocks of one tile are the products of
 // input plane pl = 2 i + s' (type A) or 2 i + 2 + s' (type B) with output plane zo = 2 i + s, i.e. tap kz = pl - zo:
 //   A: (s',s) = (0,0) kz 0 | (1,0) kz 1 | (1,1) kz 0 | (0,1) kz -1 (unused);   B: (0,0) kz 2 | (0,1) kz 1 | (1,1) kz 2 | (1,0) unused
-// -- every (plane, tap) pair exactly once, three quarters of each tile useful (wino_bww_finish_k adds the blocks up).
+// -- every (plane, tap) pair exactly once, three quarters of each tile useful (the blocks are added up at the end).
 template <int CI, int NI, bool PAIR>
 __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   constexpr int NH = CI / 8, VB = 32;
@@ -259,57 +259,48 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
     }
     __syncthreads();
   }
-  float *const out = p.wu + (size_t)blockIdx.x * NPART;
-  if (!(p.dbg & 256))
-    for (int i = tid; i < NPART / 4; i += 512) reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(part)[i];
-}
-
-// Sum of the workgroups' slabs (fixed order: four interleaved quarter sums, then their sum) and the inverse kernel
-// transform dg[kz] = G^T dU[kz] G:  slab[((kz*3 + ky)*3 + kx)][ci][co] (+)= sum_{py,px} G[py][ky] G[px][kx] dU[kz][(py,px)][ci][co].
-// One workgroup per (kz, ci): 4 slab quarters x 16 co x 16 points.
-template <int CI, bool PAIR>
-__global__ __launch_bounds__(1024) void wino_bww_finish_k(const float *wu, int nslab, float *slab, int accumulate) {
-  constexpr int MT = CI == 16 ? 3 : 2, NPART = 2 * MT * 8 * 256, CO = PAIR ? 8 : 16;
-  __shared__ float part[4][16][17], du[16][17];
-  const int tid = threadIdx.x, sg = tid >> 8, pt = (tid >> 4) & 15, co = tid & 15;
-  const int ci = blockIdx.x % CI, kz = blockIdx.x / CI;
-  const int mt = CI == 16 ? kz : (kz >> 1), row = CI == 16 ? ci : ((kz & 1) * 8 + ci);
-  const int py = pt >> 2, px = pt & 3;
-  const int pbase = ((py >> 1) * MT) * 8 + ((py & 1) * 4 + px);          // + 8 * tile: element block of (point, accumulator tile)
-  // the (up to two) 8x8 / 16x16 blocks that make up dU[kz](ci, co) -- PAIR: see wino_bww_k
-  int e0, e1 = -1;
-  if (!PAIR) {
-    e0 = (pbase + 8 * mt) * 256 + row * 16 + co;
-  } else {
-    const int c8 = co & 7;
-    if (kz == 0) { e0 = pbase * 256 + ci * 16 + c8; e1 = pbase * 256 + (8 + ci) * 16 + 8 + c8; }
-    else if (kz == 1) { e0 = pbase * 256 + (8 + ci) * 16 + c8; e1 = (pbase + 8) * 256 + ci * 16 + 8 + c8; }
-    else { e0 = (pbase + 8) * 256 + ci * 16 + c8; e1 = (pbase + 8) * 256 + (8 + ci) * 16 + 8 + c8; }
-  }
-  float s0 = 0.f, s1 = 0.f;
-  for (int s = sg; s < nslab; s += 4) {
-    s0 += wu[(size_t)s * NPART + e0];
-    if (PAIR) s1 += wu[(size_t)s * NPART + e1];
-  }
-  part[sg][pt][co] = s0 + s1;
-  __syncthreads();
-  if (sg == 0) du[pt][co] = (part[0][pt][co] + part[1][pt][co]) + (part[2][pt][co] + part[3][pt][co]);
-  __syncthreads();
-  if (tid < 9 * 16 && (tid & 15) < CO) {
-    const int tap = tid >> 4, ky = tap / 3, kx = tap % 3, c = tid & 15;
-    // G^T rows: k = 0: (1, .5, .5, 0); k = 1: (0, .5, -.5, 0); k = 2: (0, .5, .5, 1)
-    const float gy[4] = {ky == 0 ? 1.f : 0.f, 0.5f, ky == 1 ? -0.5f : 0.5f, ky == 2 ? 1.f : 0.f};
-    const float gx[4] = {kx == 0 ? 1.f : 0.f, 0.5f, kx == 1 ? -0.5f : 0.5f, kx == 2 ? 1.f : 0.f};
-    float g = 0.f;
+  // ---- inverse kernel transform dg[kz] = G^T dU[kz] G on the workgroup's partial sums (linear: it commutes with the sum
+  // over workgroups) -- the slab that leaves is an ORDINARY kernel-gradient slab [27][ci][co]; tem_reduce_slabs_multi
+  // adds the workgroups' slabs in a fixed order like those of the direct-form kernel.
+  (void)NPART;
+  constexpr int CO = PAIR ? 8 : 16;
+  float *const slab = p.slabs + (size_t)blockIdx.x * p.slab_stride;
+  if (!(p.dbg & 256)) {
+    for (int id = tid; id < 3 * CI * CO; id += 512) {        // (kz, ci, co)
+      const int co = id % CO, ci = (id / CO) % CI, kz = id / (CO * CI);
+      float du[4][4];
 #pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      float r = 0.f;
+      for (int py = 0; py < 4; ++py)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) r += gx[x] * du[y * 4 + x][c];
-      g += gy[y] * r;
+        for (int px = 0; px < 4; ++px) {
+          const int pb = ((py >> 1) * MT) * 8 + ((py & 1) * 4 + px);     // + 8 * tile: block of (point, accumulator tile)
+          float v;
+          if (!PAIR) {
+            const int mt = CI == 16 ? kz : (kz >> 1), row = CI == 16 ? ci : ((kz & 1) * 8 + ci);
+            v = part[(pb + 8 * mt) * 256 + row * 16 + co];
+          } else {                                             // the two 8x8 blocks of tap kz (see the kernel's header)
+            v = kz == 0 ? part[pb * 256 + ci * 16 + co] + part[pb * 256 + (8 + ci) * 16 + 8 + co]
+              : kz == 1 ? part[pb * 256 + (8 + ci) * 16 + co] + part[(pb + 8) * 256 + ci * 16 + 8 + co]
+                        : part[(pb + 8) * 256 + ci * 16 + co] + part[(pb + 8) * 256 + (8 + ci) * 16 + 8 + co];
+          }
+          du[py][px] = v;
+        }
+      // G^T (3x4) = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]
+      float t[3][4];
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        t[0][px] = du[0][px] + 0.5f * (du[1][px] + du[2][px]);
+        t[1][px] = 0.5f * (du[1][px] - du[2][px]);
+        t[2][px] = 0.5f * (du[1][px] + du[2][px]) + du[3][px];
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float *d = slab + (size_t)((kz * 3 + ky) * 3) * CI * CO + ci * CO + co;
+        d[0] = t[ky][0] + 0.5f * (t[ky][1] + t[ky][2]);
+        d[CI * CO] = 0.5f * (t[ky][1] - t[ky][2]);
+        d[2 * CI * CO] = 0.5f * (t[ky][1] + t[ky][2]) + t[ky][3];
+      }
     }
-    float *d = slab + (size_t)((kz * 3 + ky) * 3 + kx) * CI * CO + ci * CO + c;
-    *d = accumulate ? *d + g : g;
   }
 }
 
@@ -348,8 +339,8 @@ static int plan_bww(BDev &p, size_t *lds_bytes) {
   return best < 1e300 ? TEM_OK : TEM_EUNSUPPORTED;
 }
 
-// mode 0: launch; 1: workspace query (*ws_floats); 2: describe
-static int run_bww(const tem_bww_args *a, float *ws, hipStream_t st, int mode, int64_t *ws_floats, char *name, int name_len) {
+// mode 0: launch; 1: slab-count query (*nslab); 2: describe
+static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, char *name, int name_len) {
   const tem_view &i0 = a->in0, &dy = a->dout;
   const bool cube = a->kd == 3 && a->kh == 3 && a->kw == 3 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->pd == a->ph &&
                     a->ph == a->pw && a->pd >= 0;
@@ -385,11 +376,12 @@ static int run_bww(const tem_bww_args *a, float *ws, hipStream_t st, int mode, i
   if (rc != TEM_OK) return rc;
   const int MT = CI == 16 ? 3 : 2, npart = 2 * MT * 8 * 256;
   const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
-  if (mode == 1) { *ws_floats = (int64_t)nblocks * npart; return TEM_OK; }
+  if (nblocks > (a->nslab > 0 ? a->nslab : 1024)) return TEM_EUNSUPPORTED;
+  if (mode == 1) { *nslab = nblocks; return TEM_OK; }
   if (mode == 2) { if (name) snprintf(name, name_len, "wino_bww_k<%d, 2, %s>", CI, pair ? "true" : "false"); return TEM_OK; }
-  if (!ws || !a->slabs) return TEM_EINVAL;
+  if (!a->slabs || a->nslab != nblocks || a->accumulate) return TEM_EINVAL;
   p.magicBX = magic_for(p.BX); p.magicE = magic_for(p.E);
-  p.wu = ws;
+  p.slabs = a->slabs; p.slab_stride = a->slab_stride ? a->slab_stride : (int64_t)27 * CI * dy.C;
   {
     static int dbg = -1;
     if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
@@ -399,7 +391,7 @@ static int run_bww(const tem_bww_args *a, float *ws, hipStream_t st, int mode, i
     fprintf(stderr, "wino_bww<%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI,
             p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
   static bool attr[3] = {false, false, false};
-  auto go = [&](auto kern, auto fin, int nfin, int variant) -> int {
+  auto go = [&](auto kern, int variant) -> int {
     if (!attr[variant]) {
       hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_B);
       if (e != hipSuccess) return (int)e;
@@ -407,28 +399,26 @@ static int run_bww(const tem_bww_args *a, float *ws, hipStream_t st, int mode, i
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds_bytes, st, p);
     TEM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fin, dim3(nfin), dim3(1024), 0, st, ws, nblocks, a->slabs, a->accumulate);
-    TEM_CHECK_LAUNCH();
     return TEM_OK;
   };
-  if (pair) return go(wino_bww_k<8, 2, true>, wino_bww_finish_k<8, true>, 3 * 8, 0);
-  if (CI == 16) return go(wino_bww_k<16, 2, false>, wino_bww_finish_k<16, false>, 3 * 16, 1);
-  return go(wino_bww_k<8, 2, false>, wino_bww_finish_k<8, false>, 3 * 8, 2);
+  if (pair) return go(wino_bww_k<8, 2, true>, 0);
+  if (CI == 16) return go(wino_bww_k<16, 2, false>, 1);
+  return go(wino_bww_k<8, 2, false>, 2);
 }
 
 }  // namespace wino
 
-extern "C" int64_t tem_conv_bwd_weight_winograd_ws(const tem_bww_args *a, char *name, int32_t name_len) {
+extern "C" int tem_conv_bwd_weight_winograd_nslab(const tem_bww_args *a, char *name, int32_t name_len) {
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout)) return TEM_EINVAL;
-  int64_t n = 0;
-  int rc = wino::run_bww(a, nullptr, nullptr, 1, &n, nullptr, 0);
+  int n = 0;
+  int rc = wino::run_bww(a, nullptr, 1, &n, nullptr, 0);
   if (rc != TEM_OK) return rc;
-  if (name && name_len > 0) wino::run_bww(a, nullptr, nullptr, 2, nullptr, name, name_len);
+  if (name && name_len > 0) wino::run_bww(a, nullptr, 2, nullptr, name, name_len);
   return n;
 }
 
-extern "C" int tem_conv_bwd_weight_winograd(const tem_bww_args *a, float *workspace, tem_stream_t stream) {
+extern "C" int tem_conv_bwd_weight_winograd(const tem_bww_args *a, tem_stream_t stream) {
   TEM_CLEAR_ERR();
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout)) return TEM_EINVAL;
-  return wino::run_bww(a, workspace, (hipStream_t)stream, 0, nullptr, nullptr, 0);
+  return wino::run_bww(a, (hipStream_t)stream, 0, nullptr, nullptr, 0);
 }

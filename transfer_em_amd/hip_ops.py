@@ -275,20 +275,19 @@ def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=
     a.pd, a.ph, a.pw = _p3(p, is3d)
     namebuf = C.create_string_buffer(96)
     if wino and not bf16 and is3d and k == 3 and s == 1 and \
-            (a.in0.C + (a.in1.C if in1 is not None else 0), dout.shape[4]) in ((16, 16), (8, 8)):
-        # Winograd-domain kernel gradient (one slab, own scratch).  The library also has C_in 8 -> C_out 16; measured
-        # no faster than the direct form there (g.d2a 36.7 vs 39.2 us, d.hack 26.7 vs 26.8): 16 -> 16 and 8 -> 8 take it.
-        nws = lib.tem_conv_bwd_weight_winograd_ws(C.byref(a), namebuf, 96)
-        if nws > 0:
-            scratch = torch.empty(int(nws), dtype=torch.float32, device=in0.device)
-            ws.request(layer, call, 1, a)
-            a.slab_stride, a.nslab, a.accumulate = 0, 1, 0
+            (a.in0.C + (a.in1.C if in1 is not None else 0), dout.shape[4]) in ((16, 16), (8, 8), (8, 16)):
+        # Winograd-domain kernel gradient (ordinary slabs, one per workgroup): g.f1, g.d1a, g.d2a, d.hack
+        a.nslab = MAX_SLABS
+        nw = lib.tem_conv_bwd_weight_winograd_nslab(C.byref(a), namebuf, 96)
+        if nw > 0:
+            ws.request(layer, call, nw, a)
+            a.slab_stride, a.nslab, a.accumulate = 0, nw, 0
             ci = in0.shape[4] + (in1.shape[4] if in1 is not None else 0)
             co = dout.shape[4]
             vin, vout = in0.numel() // in0.shape[4], dout.numel() // co
             meta = dict(flops=2.0 * 27 * ci * co * vout, bytes=4.0 * (ci * vin + co * vout + 27 * ci * co),
                         kernel=namebuf.value.decode())
-            return Launch(lib.tem_conv_bwd_weight_winograd, (C.byref(a), scratch.data_ptr()), name, keep + [a, ws, scratch], meta)
+            return Launch(lib.tem_conv_bwd_weight_winograd, (C.byref(a),), name, keep + [a, ws], meta)
     a.nslab = MAX_SLABS
     n = lib.tem_conv_bwd_weight_bf16_nslab(C.byref(a), namebuf, 96) if bf16 else lib.tem_conv_bwd_weight_nslab(C.byref(a))
     if n < 1:
