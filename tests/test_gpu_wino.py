@@ -23,7 +23,7 @@ def _oracle_conv(x, w, pad):
 
 
 @pytest.mark.parametrize("ci0,ci1,co,n,slope", [(8, 8, 16, 21, 0.3), (16, 0, 16, 14, 0.3), (8, 0, 16, 17, 0.3), (16, 0, 8, 13, 1.0),
-                                                 (16, 0, 32, 15, 0.3), (16, 16, 32, 19, 0.3), (32, 0, 32, 11, 0.3), (8, 0, 8, 23, 0.3)])
+                                                 (16, 0, 32, 15, 0.3), (16, 16, 32, 19, 0.3), (32, 0, 32, 11, 0.3), (8, 0, 8, 23, 0.3), (32, 0, 16, 17, 0.3)])
 def test_winograd_forward_matches_oracle(ci0, ci1, co, n, slope):
     from transfer_em_amd import hip_ops as H
     from oracle import ops as O
@@ -48,7 +48,7 @@ def test_winograd_forward_matches_oracle(ci0, ci1, co, n, slope):
 
 
 @pytest.mark.parametrize("ci,co0,co1,n,mask", [(16, 8, 8, 12, True), (16, 16, 0, 9, False), (16, 8, 0, 15, False), (8, 16, 0, 10, False),
-                                               (32, 16, 16, 13, True), (16, 32, 0, 11, False), (32, 32, 0, 8, False), (8, 8, 0, 21, False)])
+                                               (32, 16, 16, 13, True), (16, 32, 0, 11, False), (32, 32, 0, 8, False), (8, 8, 0, 21, False), (32, 16, 0, 14, False)])
 def test_winograd_input_gradient_matches_oracle(ci, co0, co1, n, mask):
     """Operator ci -> co0 + co1 = the input-gradient of a (co0 + co1) -> ci layer: pad 2, flipped / transposed kernel, LeakyReLU'
     gate, and (mask) the forward pass's dropout keep bits on out0 with a raw second output."""
@@ -93,11 +93,11 @@ def test_winograd_falls_back_when_unsupported():
     H.require_gpu()
     dev = "cuda"
     x = torch.randn(1, 9, 9, 9, 32, device=dev)
-    theta = torch.randn(27 * 32 * 16, device=dev)
-    out = torch.empty(1, 7, 7, 7, 16, device=dev)
-    l = H.conv_launch("c", x, theta, out, 3, 1, 0, slope=0.3, wino=torch.zeros(H.wino_u_floats(32, 16), device=dev))   # 32 -> 16: not compiled
+    theta = torch.randn(27 * 32 * 8, device=dev)
+    out = torch.empty(1, 7, 7, 7, 8, device=dev)
+    l = H.conv_launch("c", x, theta, out, 3, 1, 0, slope=0.3, wino=torch.zeros(4 * H.WINO_U_FLOATS, device=dev))   # 32 -> 8: not compiled
     assert not l.meta["kernel"].startswith("wino_conv_k")
-    assert not H.wino_channels(32, 16) and H.wino_channels(16, 16)
+    assert not H.wino_channels(32, 8) and H.wino_channels(16, 16)
     x16 = torch.randn(1, 9, 9, 9, 16, device=dev)
     th16 = torch.randn(27 * 16 * 16, device=dev)
     out16 = torch.empty(1, 7, 7, 7, 16, device=dev)

@@ -159,11 +159,11 @@ def test_paramset_winograd_tables():
     from transfer_em_amd.models.generator import generator_param_shapes
     from transfer_em_amd.models.params import ParamSet
     P = ParamSet(generator_param_shapes(True, 8), "cpu", seed=0)
-    assert set(P._u_fwd) == {"d1a", "d2a", "u2a", "mid", "f1"}              # 8->8, 8->16, 16->32, 32->32, 16->16
-    assert set(P._u_bwd) == {"d1a", "d2a", "mid", "u1a", "f1"}              # operators 8->8, 16->8, 32->32, 16->32, 16->16 (u2a's 32->16: none)
+    assert set(P._u_fwd) == {"d1a", "d2a", "u2a", "mid", "u1a", "f1"}       # 8->8, 8->16, 16->32, 32->32, 32->16, 16->16
+    assert set(P._u_bwd) == {"d1a", "d2a", "u2a", "mid", "u1a", "f1"}       # operators 8->8, 16->8, 32->16, 32->32, 16->32, 16->16
     spans = sorted((e[1], e[1] + H.wino_u_floats(e[2], e[3])) for e in P._u_entries)
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] == P.theta_u.numel()
-    assert P.u("c0") is None and P.u("u1a") is None and P.u("u1a", bwd=True).numel() == H.wino_u_floats(16, 32)
+    assert P.u("c0") is None and P.u("u1a").numel() == H.wino_u_floats(32, 16) and P.u("u1a", bwd=True).numel() == H.wino_u_floats(16, 32)
     assert H.wino_u_floats(8, 8) == 8192 and H.wino_u_floats(32, 32) == 4 * 2 * H.WINO_U_FLOATS
     P2 = ParamSet(generator_param_shapes(False, 8), "cpu", seed=0)          # 2-D networks: no Winograd layer
     assert P2._utable is None and P2.winograd_launch() is None

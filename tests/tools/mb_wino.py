@@ -33,6 +33,8 @@ cases = (
     ("mid bd 32->16+16 52 p2", (32, 0), (16, 16), 52, 2, True, dict(gate=True, mask=True)),
     ("u1a bd 16->32 50 p2", (16, 0), (32, 0), 50, 2, True, dict(gate=True)),
     ("d.d2a fwd 16->32 44", (16, 0), (32, 0), 44, 0, False, dict(slope=0.3)),
+    ("u1a fwd 32->16 52", (32, 0), (16, 0), 52, 0, False, dict(slope=0.3)),
+    ("d.d2a bd 32->16 42 p2", (32, 0), (16, 0), 42, 2, True, dict(gate=True)),
     ("d3a fwd 32->32 20", (32, 0), (32, 0), 20, 0, False, dict(slope=0.3)),
     ("d3a bd 32->32 18 p2", (32, 0), (32, 0), 18, 2, True, dict(gate=True)),
 )

@@ -66,8 +66,9 @@ struct Dev {
 // EP: compiled epilogue -- 0: LeakyReLU(slope) (forward layers); 1: LeakyReLU' gate on the saved activation (input-gradients);
 // 2: gate, the forward pass's dropout keep bits and a second output tensor (input-gradient of a concat through Dropout)
 // C_out = 32: two 16-channel column blocks; the 8 waves are (2 row blocks) x (2 column blocks) x (2 output planes) and a
-// workgroup owns 32 tiles.  C_in = 32 (STREAM): the transformed kernel (196 KB) does not fit beside the ring; it streams
-// through two 32 KB LDS buffers in (z tap, channel-half pair) chunks, one chunk ahead of its use.
+// workgroup owns 32 tiles.  C_in = 32 (STREAM): the transformed kernel (98 / 196 KB) does not fit beside the ring; it
+// streams through two 16 / 32 KB LDS buffers in (z tap, channel-half pair) chunks, one chunk ahead of its use.  32 -> 16:
+// the ring of a 32-channel input leaves room for 48 tiles (three row blocks; the fourth pair of waves idles along).
 template <int CI, int CO, int NI, int EP>
 __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   constexpr int NH = CI / 8, VB = 32;                        // channel-pair halves = sub-images (8 channels); bytes per sub-image voxel
@@ -80,7 +81,6 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   constexpr bool PAIR = CI == 8 && CO == 8;
   constexpr int NKZ = PAIR ? 4 : 3;                          // z passes per step
   constexpr int UCH = 2 * NB * 16 * 128;                     // floats per streamed chunk: 2 channel halves x NB x 16 points x fragment
-  static_assert(!STREAM || NB == 2, "streamed U: 32 -> 32 only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char *const ring = reinterpret_cast<char *>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -549,6 +549,7 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   WINO_CASE(16, 8, 2, 0) WINO_CASE(16, 8, 2, 1)
   WINO_CASE(16, 32, 2, 0) WINO_CASE(16, 32, 2, 1)
   WINO_CASE(32, 32, 2, 0) WINO_CASE(32, 32, 2, 1) WINO_CASE(32, 32, 2, 2)
+  WINO_CASE(32, 16, 2, 0) WINO_CASE(32, 16, 2, 1)
 #undef WINO_CASE
   return TEM_EUNSUPPORTED;
 }

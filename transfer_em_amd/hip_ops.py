@@ -416,8 +416,8 @@ def wino_u_floats(ci, co):
 
 def wino_channels(ci, co):
     """Channel pairs (of the OPERATOR: the input-gradient of a ci -> co layer is a co -> ci operator) that the Winograd
-    kernel is built for and wins on (32 -> 16 has no form that fits the LDS)."""
-    return (ci, co) in ((8, 8), (16, 16), (8, 16), (16, 8), (16, 32), (32, 32))
+    kernel is built for."""
+    return (ci, co) in ((8, 8), (16, 16), (8, 16), (16, 8), (16, 32), (32, 32), (32, 16))
 
 
 def pack_weights_launch(name, theta, theta_h, theta_ht, table_dev, nlayers):

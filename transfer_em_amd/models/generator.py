@@ -196,7 +196,7 @@ class GenForward:
                     slope=H.LEAKY, dropout=dr(0), drop_frame=(lo("u2b"), e["u2b"]), keep_mask=km(0, 1), **kw))
         L.append(cv("g.mid", A["u2b"], wf("mid"), A["mid"], 3, 1, pc(0, 1, "u2b", "mid"), in1=self.skip1,
                     slope=H.LEAKY, wino=wu("mid"), **kw))
-        L.append(cv("g.u1a", A["mid"], wf("u1a"), A["u1a"], 3, 1, pc(0, 1, "mid", "u1a"), slope=H.LEAKY, **kw))
+        L.append(cv("g.u1a", A["mid"], wf("u1a"), A["u1a"], 3, 1, pc(0, 1, "mid", "u1a"), slope=H.LEAKY, wino=wu("u1a"), **kw))
         L.append(cv("g.u1b", A["u1a"], wT("u1b"), A["u1b"], 4, 2, pt(1, 2, "u1a", "u1b"), transposed=True,
                     slope=H.LEAKY, dropout=dr(1), drop_frame=(lo("u1b"), e["u1b"]), keep_mask=km(1, 1), **kw))
         L.append(cv("g.f1", A["u1b"], wf("f1"), A["f1"], 3, 1, pc(0, 1, "u1b", "f1"), in1=self.skip0,
