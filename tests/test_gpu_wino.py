@@ -108,7 +108,8 @@ def test_winograd_falls_back_when_unsupported():
 
 
 @pytest.mark.parametrize("ci0,ci1,n,pad,co", [(8, 8, 13, 0, 16), (16, 0, 10, 0, 16), (8, 0, 11, 0, 16), (16, 0, 9, 2, 16),
-                                              (8, 0, 12, 0, 8), (8, 0, 9, 2, 8)])
+                                              (8, 0, 12, 0, 8), (8, 0, 9, 2, 8), (16, 0, 11, 0, 32), (16, 16, 10, 0, 16), (16, 16, 9, 0, 32),
+                                              (32, 0, 8, 2, 32)])
 def test_winograd_kernel_gradient_matches_oracle(ci0, ci1, n, pad, co):
     """tem_conv_bwd_weight_winograd (one slab per workgroup, deterministic) against the oracle's float64 kernel gradient."""
     import ctypes as C

@@ -15,8 +15,11 @@ def t(launches, n=20):
     return a.elapsed_time(b) / n * 1e3
 small = "small" in sys.argv[1:]
 for name, (ci0, ci1), co, nin in (("d1a 8->8 128", (8, 0), 8, 128), ("d1a cone 8->8 104", (8, 0), 8, 104), ("f1 8+8->16 100", (8, 8), 16, 100), ("d2a 8->16 62", (8, 0), 16, 62), ("hack 8->16 46", (8, 0), 16, 46),
-                                  ("f1 cone 8+8->16 64", (8, 8), 16, 64)):
+                                  ("f1 cone 8+8->16 64", (8, 8), 16, 64), ("mid 16+16->32 54", (16, 16), 32, 54), ("mid cone 38", (16, 16), 32, 38),
+                                  ("u1a 32->16 52", (32, 0), 16, 52), ("u2a 16->32 29", (16, 0), 32, 29), ("d.d2a 16->32 44", (16, 0), 32, 44),
+                                  ("d3a 32->32 20", (32, 0), 32, 20)):
     if small: nin = min(nin, 23)
+    H.WINO_MIN_VOXELS = 0
     ci = ci0 + ci1
     torch.manual_seed(2)
     x = torch.randn(1, nin, nin, nin, ci, device=dev)

@@ -52,18 +52,28 @@ struct BDev {
 // input plane pl = 2 i + s' (type A) or 2 i + 2 + s' (type B) with output plane zo = 2 i + s, i.e. tap kz = pl - zo:
 //   A: (s',s) = (0,0) kz 0 | (1,0) kz 1 | (1,1) kz 0 | (0,1) kz -1 (unused);   B: (0,0) kz 2 | (0,1) kz 1 | (1,1) kz 2 | (1,0) unused
 // -- every (plane, tap) pair exactly once, three quarters of each tile useful (the blocks are added up at the end).
-template <int CI, int NI, bool PAIR>
+// 32 channels on either side: the layer is CIH x NB independent (16-channel input half, 16-channel output block)
+// problems over the same planes -- a wave pair (the two point halves) owns one such combination and fewer tile subsets
+// remain (NS = 4 / (CIH NB)); 32 input channels: 32 tiles per workgroup (the ring of a 32-channel input is twice as big).
+template <int CI, int CO, int NI, bool PAIR>
 __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   constexpr int NH = CI / 8, VB = 32;
-  constexpr int MT = CI == 16 ? 3 : 2;                       // accumulator tiles per point: (tap, ci) row tiles, or types A / B
+  constexpr int MT = CI >= 16 ? 3 : 2;                       // accumulator tiles per point: (tap, ci) row tiles, or types A / B
   constexpr int NZO = PAIR ? 1 : 2;                          // output planes handled one after the other per step
-  static_assert(!PAIR || CI == 8, "plane-pair form: 8 -> 8 channels");
+  constexpr int CIH = CI >= 16 ? CI / 16 : 1, NB = PAIR ? 1 : CO / 16, NC = CIH * NB, NS = 4 / NC;
+  constexpr int TB = CI == 32 ? 32 : 64;                     // tiles per workgroup
+  constexpr int JW = TB / NS / 8;                            // tile-pair rounds per wave and plane (8 tiles each)
+  constexpr bool PREF = JW <= 2;                             // gradient voxels of the next plane prefetched (register budget)
+  static_assert(!PAIR || (CI == 8 && CO == 8), "plane-pair form: 8 -> 8 channels");
+  static_assert(JW == 2 || JW == 4, "tile rounds per wave");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char *const ring = reinterpret_cast<char *>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, q = lane >> 4;
-  const int sub = wave >> 1, ph = wave & 1;                  // 16-tile subset of the block; point rows py = 2 ph, 2 ph + 1
+  const int ph = wave & 1;                                   // point rows py = 2 ph, 2 ph + 1
+  const int cmb = (wave >> 1) % NC, sub = (wave >> 1) / NC;  // (input half, output block) combination; tile subset of the block
+  const int cih = cmb % CIH, nb = cmb / CIH;
 
   int seg = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int zseg = seg % p.zsegs; seg /= p.zsegs;
@@ -117,20 +127,20 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   // sub-images / ring slots start 32 bytes past a multiple of 128 (subb, slotb = 32 mod 128): a half-wave's read = 16
   // rows (channels 0..7 | 8..15, or taps 0 | 1 for C_in 8) x the tiles of lane groups q and q + 1 (two tiles = 64 bytes
   // apart) then covers the 32 banks exactly once.
-  const int ciA = CI == 16 ? m : (m & 7);
+  const int ciA = CI >= 16 ? 16 * cih + m : (m & 7);          // the lane's input channel (A rows)
   const int rowb = p.E * VB;
-  // tile pair j of the lane: tiles t0 = 16 sub + 8 j + 2 q (k-step 2 j, the .x of the packed values) and t0 + 1 (k-step
+  // tile pair j of the lane: tiles t0 = 8 JW sub + 8 j + 2 q (k-step 2 j, the .x of the packed values) and t0 + 1 (k-step
   // 2 j + 1, .y) -- x neighbours (BX is even): one ds_read2_b32 fetches a raw value of both
-  int abase[2], dybase[2];                                  // byte offset of t0's raw origin inside a plane image; t0's gradient voxel (0,0)
+  int abase[JW], dybase[JW];                                // byte offset of t0's raw origin inside a plane image; t0's gradient voxel (0,0)
   uint32_t dyok = 0;                                         // bit 8 j + 4 i + o4: gradient voxel o4 of tile t0 + i exists
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int t = sub * 16 + 8 * j + 2 * q;
+  for (int j = 0; j < JW; ++j) {
+    const int t = sub * (8 * JW) + 8 * j + 2 * q;
     const int tc = min(t, ntile - 2);
     const int ty = (int)fdiv((uint32_t)tc, (uint32_t)p.BX, p.magicBX), tx = tc - ty * p.BX;
     abase[j] = (ciA >> 3) * p.subb + (4 * ty * p.E + tx) * VB + (ciA & 7) * 4;
     const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-    dybase[j] = oy * p.dH + ox * p.dW + (PAIR ? (m & 7) + (m >> 3) * p.dD : m);        // PAIR: column block = output plane
+    dybase[j] = oy * p.dH + ox * p.dW + (PAIR ? (m & 7) + (m >> 3) * p.dD : 16 * nb + m);   // PAIR: column block = output plane
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -145,11 +155,11 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto load_dy = [&](f32x2 (&g)[2][4], int oz) {             // the lane's 2x2 gradient voxels of its 4 tiles, plane oz
+  auto load_dy = [&](f32x2 (&g)[JW][4], int oz) {            // the lane's 2x2 gradient voxels of its 2 JW tiles, plane oz
     const bool zok = oz + (PAIR ? (m >> 3) : 0) < p.OD;      // (PAIR: plane oz + column block)
     const float *const base = dyn + (zok ? oz : 0) * p.dD;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JW; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -163,77 +173,106 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   __syncthreads();
 
   // The point half ph is wave-uniform; the loop body is compiled once per value (static row indices: no selects).
+  auto load_dy_pair = [&](f32x2 (&g)[4], int oz, int j) {    // ... of tile pair j only
+    const bool zok = oz + (PAIR ? (m >> 3) : 0) < p.OD;
+    const float *const base = dyn + (zok ? oz : 0) * p.dD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int o4 = 0; o4 < 4; ++o4) {
+        const bool ok = zok && ((dyok >> (8 * j + 4 * i + o4)) & 1u);
+        const float v = base[ok ? dybase[j] + (o4 >> 1) * p.dH + (2 * i + (o4 & 1)) * p.dW : 0];
+        if (i) g[o4].y = ok ? v : 0.f;
+        else g[o4].x = ok ? v : 0.f;
+      }
+  };
   auto run = [&](auto phc) {
     constexpr int PH = decltype(phc)::value;
-    f32x2 gcur[2][4], gnext[2][4];                           // 2x2 gradient voxels of the lane's tile pairs (k-steps 2 j, 2 j + 1)
-    if (nsteps > 0) load_dy(gcur, 2 * tz0);
+    f32x2 gcur[PREF ? JW : 1][4], gnext[PREF ? JW : 1][4];   // 2x2 gradient voxels of the lane's tile pairs (k-steps 2 j, 2 j + 1)
+    if constexpr (PREF) {
+      if (nsteps > 0) load_dy(gcur, 2 * tz0);
+    }
     for (int step = 0; step < nsteps; ++step) {
       const int tz = tz0 + step, izb = 2 * tz - p.P;
       const bool more = step + 1 < nsteps;
       const int sA = (step & 1) ? 2 : 0;
+      // one (accumulator tile mt, tile pair j) block of output plane zo: 3 raw rows x 4 of both tiles, transforms, 16 MFMAs
+      auto block = [&](int zo, int mt, int j, const f32x2 (&gy)[4]) {
+        // input plane of this lane's rows: tap kz = mt (C_in >= 16) or 2 mt + (m >> 3) (C_in 8; rows 8..15 of tile 1 repeat tap 2)
+        const int kzl = CI >= 16 ? mt : min(2, 2 * mt + (m >> 3));
+        const int pl = PAIR ? 2 * mt + (m >> 3) : zo + kzl;    // PAIR: type A rows read planes 0 | 1, type B planes 2 | 3
+        const char *plane = ring + ((pl < 2 ? sA : 2 - sA) + (pl & 1)) * p.slotb;
+        // raw rows PH .. PH + 2 of the 4x4 tile (the two point rows of this half need three raw rows)
+        f32x2 v[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int dx = 0; dx < 4; ++dx) {
+            const int off = (2 * (PH + i) + (dx & 1)) * rowb + (dx >> 1) * VB;     // row (yr, o) of the image, x half
+            const float *src = reinterpret_cast<const float *>(plane + abase[j] + off);
+            v[i][dx] = f32x2{src[0], src[VB / 4]};                                  // tiles t0, t0 + 1: one ds_read2_b32
+          }
+        if (PAIR ? (mt == 0 && j == JW - 1) : (zo == 1 && mt == 0 && j == JW - 1)) {
+          // every wave is past the step's planes 0 and 1 (zo = 1 starts at plane 1 = its tap 0): they make room for
+          // the next step's planes 2, 3
+          __syncthreads();
+          if (more && !(p.dbg & 4)) { dma_plane(izb + 4, sA); dma_plane(izb + 5, sA + 1); }
+        }
+        // B^T on y for point rows 2 PH, 2 PH + 1, then on x
+        f32x2 vp[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          vp[0][c] = PH ? v[1][c] - v[0][c] : v[0][c] - v[2][c];
+          vp[1][c] = PH ? v[0][c] - v[2][c] : v[1][c] + v[2][c];
+        }
+        bt4(vp[0][0], vp[0][1], vp[0][2], vp[0][3]);
+        bt4(vp[1][0], vp[1][1], vp[1][2], vp[1][3]);
+        // Z = A dY A^T for the lane's (co, tile pair), the same two point rows (recomputed per tap: cheaper than
+        // keeping it live)
+        f32x2 zv[2][4];
+        {
+          const f32x2 y00 = gy[0], y01 = gy[1], y10 = gy[2], y11 = gy[3];
+          const f32x2 a0 = PH ? y00 - y10 : y00, b0 = PH ? y01 - y11 : y01;         // point row 2 PH
+          const f32x2 a1 = PH ? -y10 : y00 + y10, b1 = PH ? -y11 : y01 + y11;       // point row 2 PH + 1
+          zv[0][0] = a0; zv[0][1] = a0 + b0; zv[0][2] = a0 - b0; zv[0][3] = -b0;
+          zv[1][0] = a1; zv[1][1] = a1 + b1; zv[1][2] = a1 - b1; zv[1][3] = -b1;
+        }
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt)
+          acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[pt >> 2][pt & 3].x, zv[pt >> 2][pt & 3].x, acc[mt][pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt)
+          acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[pt >> 2][pt & 3].y, zv[pt >> 2][pt & 3].y, acc[mt][pt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);               // one tile pair's raw rows in flight at a time (register budget)
+      };
 #pragma unroll
       for (int zo = 0; zo < NZO; ++zo) {
-        // prefetch the gradient voxels of the next output plane (next zo / next step) under this plane's MFMAs
-        if (!(p.dbg & 512)) {
-          if (!PAIR && zo == 0) load_dy(gnext, 2 * tz + 1);
-          else if (more) load_dy(gnext, 2 * tz + 2);
-        }
+        if constexpr (PREF) {
+          // the gradient voxels of the next output plane (next zo / next step) are fetched under this plane's MFMAs
+          if (!(p.dbg & 512)) {
+            if (!PAIR && zo == 0) load_dy(gnext, 2 * tz + 1);
+            else if (more) load_dy(gnext, 2 * tz + 2);
+          }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          // input plane of this lane's rows: tap kz = mt (C_in 16) or 2 mt + (m >> 3) (C_in 8; rows 8..15 of tile 1 repeat tap 2)
-          const int kzl = CI == 16 ? mt : min(2, 2 * mt + (m >> 3));
-          const int pl = PAIR ? 2 * mt + (m >> 3) : zo + kzl;  // PAIR: type A rows read planes 0 | 1, type B planes 2 | 3
-          const char *plane = ring + ((pl < 2 ? sA : 2 - sA) + (pl & 1)) * p.slotb;
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {                        // tile pair: k-steps 2 j (.x) and 2 j + 1 (.y)
-            // raw rows PH .. PH + 2 of the 4x4 tile (the two point rows of this half need three raw rows)
-            f32x2 v[3][4];
+            for (int j = 0; j < JW; ++j) block(zo, mt, j, gcur[j]);
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+          for (int jj = 0; jj < JW; ++jj)
 #pragma unroll
-              for (int dx = 0; dx < 4; ++dx) {
-                const int off = (2 * (PH + i) + (dx & 1)) * rowb + (dx >> 1) * VB;     // row (yr, o) of the image, x half
-                const float *src = reinterpret_cast<const float *>(plane + abase[j] + off);
-                v[i][dx] = (p.dbg & 2) ? f32x2{1.f, 2.f} : f32x2{src[0], src[VB / 4]};  // tiles t0, t0 + 1: one ds_read2_b32
-              }
-            if (PAIR ? (mt == 0 && j == 1) : (zo == 1 && mt == 0 && j == 1)) {
-              // every wave is past the step's planes 0 and 1 (zo = 1 starts at plane 1 = its tap 0): they make room for
-              // the next step's planes 2, 3
-              __syncthreads();
-              if (more && !(p.dbg & 4)) { dma_plane(izb + 4, sA); dma_plane(izb + 5, sA + 1); }
-            }
-            // B^T on y for point rows 2 PH, 2 PH + 1, then on x
-            f32x2 vp[2][4];
+            for (int i = 0; i < 4; ++i) gcur[jj][i] = gnext[jj][i];
+        } else {
+          // four tile pairs per wave: pair-major order, the gradient voxels of pair j + 1 fetched under pair j's three taps
+          load_dy_pair(gcur[0], 2 * tz + zo, 0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              vp[0][c] = PH ? v[1][c] - v[0][c] : v[0][c] - v[2][c];
-              vp[1][c] = PH ? v[0][c] - v[2][c] : v[1][c] + v[2][c];
-            }
-            bt4(vp[0][0], vp[0][1], vp[0][2], vp[0][3]);
-            bt4(vp[1][0], vp[1][1], vp[1][2], vp[1][3]);
-            // Z = A dY A^T for the lane's (co, tile pair), the same two point rows (recomputed per tap: cheaper than
-            // keeping it live)
-            f32x2 zv[2][4];
-            {
-              const f32x2 y00 = gcur[j][0], y01 = gcur[j][1], y10 = gcur[j][2], y11 = gcur[j][3];
-              const f32x2 a0 = PH ? y00 - y10 : y00, b0 = PH ? y01 - y11 : y01;         // point row 2 PH
-              const f32x2 a1 = PH ? -y10 : y00 + y10, b1 = PH ? -y11 : y01 + y11;       // point row 2 PH + 1
-              zv[0][0] = a0; zv[0][1] = a0 + b0; zv[0][2] = a0 - b0; zv[0][3] = -b0;
-              zv[1][0] = a1; zv[1][1] = a1 + b1; zv[1][2] = a1 - b1; zv[1][3] = -b1;
-            }
+          for (int j = 0; j < JW; ++j) {
+            if (j + 1 < JW) load_dy_pair(gnext[0], 2 * tz + zo, j + 1);
 #pragma unroll
-            for (int pt = 0; pt < 8; ++pt)
-              acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[pt >> 2][pt & 3].x, zv[pt >> 2][pt & 3].x, acc[mt][pt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) block(zo, mt, j, gcur[0]);
 #pragma unroll
-            for (int pt = 0; pt < 8; ++pt)
-              acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[pt >> 2][pt & 3].y, zv[pt >> 2][pt & 3].y, acc[mt][pt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);               // one tile pair's raw rows in flight at a time (register budget)
+            for (int i = 0; i < 4; ++i) gcur[0][i] = gnext[0][i];
           }
         }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) gcur[jj][i] = gnext[jj][i];
       }
       __syncthreads();
     }
@@ -241,90 +280,94 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   if (ph) run(std::integral_constant<int, 1>{});
   else run(std::integral_constant<int, 0>{});
 
-  // ---- sum the four tile subsets through LDS in a fixed order, one Winograd-domain slab per workgroup:
-  //   part[((ph * MT + mt) * 8 + pt) * 256 + row * 16 + co],  row = 4 q + r
-  float *const part = lds;
-  constexpr int NPART = 2 * MT * 8 * 256;
-  for (int s4 = 0; s4 < ((p.dbg & 64) ? 1 : 4); ++s4) {
-    if (sub == s4) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int pt = 0; pt < 8; ++pt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float *d = part + ((ph * MT + mt) * 8 + pt) * 256 + (4 * q + r) * 16 + m;
-            *d = s4 == 0 ? acc[mt][pt][r] : *d + acc[mt][pt][r];
-          }
-    }
-    __syncthreads();
-  }
-  // ---- inverse kernel transform dg[kz] = G^T dU[kz] G on the workgroup's partial sums (linear: it commutes with the sum
+  // ---- per (input half, output block) combination: sum its NS tile subsets through LDS in a fixed order,
+  //   part[((ph * MT + mt) * 8 + pt) * 256 + row * 16 + co],  row = 4 q + r,
+  // then the inverse kernel transform dg[kz] = G^T dU[kz] G on the workgroup's partial sums (linear: it commutes with the sum
   // over workgroups) -- the slab that leaves is an ORDINARY kernel-gradient slab [27][ci][co]; tem_reduce_slabs_multi
   // adds the workgroups' slabs in a fixed order like those of the direct-form kernel.
-  (void)NPART;
-  constexpr int CO = PAIR ? 8 : 16;
+  float *const part = lds;
+  constexpr int COB = PAIR ? 8 : 16;                           // columns of the combination's block
   float *const slab = p.slabs + (size_t)blockIdx.x * p.slab_stride;
-  if (!(p.dbg & 256)) {
-    for (int id = tid; id < 3 * CI * CO; id += 512) {        // (kz, ci, co)
-      const int co = id % CO, ci = (id / CO) % CI, kz = id / (CO * CI);
-      float du[4][4];
+  for (int c = 0; c < NC; ++c) {
+    for (int s4 = 0; s4 < NS; ++s4) {
+      if (cmb == c && sub == s4) {
 #pragma unroll
-      for (int py = 0; py < 4; ++py)
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float *d = part + ((ph * MT + mt) * 8 + pt) * 256 + (4 * q + r) * 16 + m;
+              *d = s4 == 0 ? acc[mt][pt][r] : *d + acc[mt][pt][r];
+            }
+      }
+      __syncthreads();
+    }
+    const int ci0 = CI >= 16 ? 16 * (c % CIH) : 0, co0 = 16 * (c / CIH);
+    constexpr int CIB = CI >= 16 ? 16 : CI;
+    if (!(p.dbg & 256)) {
+      for (int id = tid; id < 3 * CIB * COB; id += 512) {    // (kz, ci, co) of the combination's block
+        const int co = id % COB, ci = (id / COB) % CIB, kz = id / (COB * CIB);
+        float du[4][4];
+#pragma unroll
+        for (int py = 0; py < 4; ++py)
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            const int pb = ((py >> 1) * MT) * 8 + ((py & 1) * 4 + px);     // + 8 * tile: block of (point, accumulator tile)
+            float v;
+            if (!PAIR) {
+              const int mt = CI >= 16 ? kz : (kz >> 1), row = CI >= 16 ? ci : ((kz & 1) * 8 + ci);
+              v = part[(pb + 8 * mt) * 256 + row * 16 + co];
+            } else {                                           // the two 8x8 blocks of tap kz (see the kernel's header)
+              v = kz == 0 ? part[pb * 256 + ci * 16 + co] + part[pb * 256 + (8 + ci) * 16 + 8 + co]
+                : kz == 1 ? part[pb * 256 + (8 + ci) * 16 + co] + part[(pb + 8) * 256 + ci * 16 + 8 + co]
+                          : part[(pb + 8) * 256 + ci * 16 + co] + part[(pb + 8) * 256 + (8 + ci) * 16 + 8 + co];
+            }
+            du[py][px] = v;
+          }
+        // G^T (3x4) = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]
+        float t[3][4];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-          const int pb = ((py >> 1) * MT) * 8 + ((py & 1) * 4 + px);     // + 8 * tile: block of (point, accumulator tile)
-          float v;
-          if (!PAIR) {
-            const int mt = CI == 16 ? kz : (kz >> 1), row = CI == 16 ? ci : ((kz & 1) * 8 + ci);
-            v = part[(pb + 8 * mt) * 256 + row * 16 + co];
-          } else {                                             // the two 8x8 blocks of tap kz (see the kernel's header)
-            v = kz == 0 ? part[pb * 256 + ci * 16 + co] + part[pb * 256 + (8 + ci) * 16 + 8 + co]
-              : kz == 1 ? part[pb * 256 + (8 + ci) * 16 + co] + part[(pb + 8) * 256 + ci * 16 + 8 + co]
-                        : part[(pb + 8) * 256 + ci * 16 + co] + part[(pb + 8) * 256 + (8 + ci) * 16 + 8 + co];
-          }
-          du[py][px] = v;
+          t[0][px] = du[0][px] + 0.5f * (du[1][px] + du[2][px]);
+          t[1][px] = 0.5f * (du[1][px] - du[2][px]);
+          t[2][px] = 0.5f * (du[1][px] + du[2][px]) + du[3][px];
         }
-      // G^T (3x4) = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]
-      float t[3][4];
 #pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        t[0][px] = du[0][px] + 0.5f * (du[1][px] + du[2][px]);
-        t[1][px] = 0.5f * (du[1][px] - du[2][px]);
-        t[2][px] = 0.5f * (du[1][px] + du[2][px]) + du[3][px];
-      }
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        float *d = slab + (size_t)((kz * 3 + ky) * 3) * CI * CO + ci * CO + co;
-        d[0] = t[ky][0] + 0.5f * (t[ky][1] + t[ky][2]);
-        d[CI * CO] = 0.5f * (t[ky][1] - t[ky][2]);
-        d[2 * CI * CO] = 0.5f * (t[ky][1] + t[ky][2]) + t[ky][3];
+        for (int ky = 0; ky < 3; ++ky) {
+          float *d = slab + (size_t)((kz * 3 + ky) * 3) * CI * CO + (ci0 + ci) * CO + co0 + co;
+          d[0] = t[ky][0] + 0.5f * (t[ky][1] + t[ky][2]);
+          d[CI * CO] = 0.5f * (t[ky][1] - t[ky][2]);
+          d[2 * CI * CO] = 0.5f * (t[ky][1] + t[ky][2]) + t[ky][3];
+        }
       }
     }
+    if (c + 1 < NC) __syncthreads();                         // the buffer is reused by the next combination
   }
 }
 
 // ------------------------------------------------------------------------------------------ host
 constexpr int LDS_MAX_B = 160 * 1024;
 
-template <int CI, int NI>
+template <int CI, int CO, int NI>
 static int plan_bww(BDev &p, size_t *lds_bytes) {
-  constexpr int NH = CI / 8, MT = CI == 16 ? 3 : 2;
+  constexpr int NH = CI / 8, MT = CI >= 16 ? 3 : 2;
+  constexpr int CIH = CI >= 16 ? CI / 16 : 1, NB = CO / 16 > 0 ? CO / 16 : 1, NC = CIH * NB, TB = CI == 32 ? 32 : 64;
   const int TY = (p.OH + 1) / 2, TX = (p.OW + 1) / 2;
   double best = 1e300;
   for (int by = 1; by <= TY && by <= 64; ++by)
     for (int bx = 1; bx <= TX && bx <= 64; ++bx) {
       const int nt = by * bx;
-      if (nt > 64) continue;
+      if (nt > TB) continue;
       const int E = bx + 1, plv = (2 * by + 2) * 2 * E;
       const int ndma = (plv * 32 + 1023) / 1024;
       if (bx & 1) continue;                                            // tile pairs (t, t + 1) must not wrap rows
       const int subb = ndma * 1024 + 32, slotb = ((NH * subb + 127) / 128) * 128 + (NH == 1 ? 32 : 0);
-      const size_t bytes = std::max((size_t)4 * slotb, (size_t)2 * MT * 8 * 256 * 4);
+      const size_t bytes = std::max((size_t)4 * slotb, (size_t)2 * MT * 8 * 256 * 4);   // ring; reused by the final sums
       if (bytes > (size_t)LDS_MAX_B || ndma > 8 * NI) continue;
       const int nby = (TY + by - 1) / by, nbx = (TX + bx - 1) / bx;
       const int cols = p.N * nby * nbx;
-      const double step = 2.0 * 2 * MT * 32 * 45.0 + 4000.0;          // two waves per SIMD, 2 planes x MT x 4 k-steps x 8 MFMAs each
+      const double step = 2.0 * 2 * MT * 32 * 45.0 * NC * (TB / 64.0) + 4000.0;   // two waves per SIMD, 2 planes x MT x k-steps x 8 MFMAs each
       const double pro = 8000.0 + 4.0 * slotb / 10.0 + 6000.0;         // prologue + the final LDS reduction and slab write
       for (int zs = 1; zs <= p.NTZ; ++zs) {
         const int zper = (p.NTZ + zs - 1) / zs, zsegs = (p.NTZ + zper - 1) / zper;
@@ -362,7 +405,11 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
     CI += i1.C;
   }
   const bool pair = dy.C == 8 && CI == 8;
-  if (!(pair || (dy.C == 16 && (CI == 16 || CI == 8))) || dy.N != i0.N) return TEM_EUNSUPPORTED;
+  const int CO = dy.C;
+  // variants: 0: 8 -> 8 (plane pairs), 1: 16 -> 16, 2: 8 -> 16, 3: 16 -> 32, 4: 32 -> 16, 5: 32 -> 32
+  const int variant = pair ? 0 : (CI == 16 && CO == 16) ? 1 : (CI == 8 && CO == 16) ? 2 : (CI == 16 && CO == 32) ? 3
+                    : (CI == 32 && CO == 16) ? 4 : (CI == 32 && CO == 32) ? 5 : -1;
+  if (variant < 0 || dy.N != i0.N) return TEM_EUNSUPPORTED;
   if (dy.D != i0.D + 2 * a->pd - 2 || dy.H != i0.H + 2 * a->ph - 2 || dy.W != i0.W + 2 * a->pw - 2) return TEM_ESHAPE;
   p.N = i0.N; p.D = i0.D; p.H = i0.H; p.W = i0.W;
   p.span0 = (int)(((int64_t)(i0.H - 1) * p.i0H + (int64_t)(i0.W - 1) * p.i0W + i0.C) * 4);
@@ -372,13 +419,14 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
   p.NTZ = (p.OD + 1) / 2;
   p.P = a->pd;
   size_t lds_bytes = 0;
-  const int rc = CI == 16 ? plan_bww<16, 2>(p, &lds_bytes) : plan_bww<8, 2>(p, &lds_bytes);
+  const int rc = variant == 0 ? plan_bww<8, 8, 2>(p, &lds_bytes) : variant == 1 ? plan_bww<16, 16, 2>(p, &lds_bytes)
+               : variant == 2 ? plan_bww<8, 16, 2>(p, &lds_bytes) : variant == 3 ? plan_bww<16, 32, 2>(p, &lds_bytes)
+               : variant == 4 ? plan_bww<32, 16, 2>(p, &lds_bytes) : plan_bww<32, 32, 2>(p, &lds_bytes);
   if (rc != TEM_OK) return rc;
-  const int MT = CI == 16 ? 3 : 2, npart = 2 * MT * 8 * 256;
   const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
   if (nblocks > (a->nslab > 0 ? a->nslab : 1024)) return TEM_EUNSUPPORTED;
   if (mode == 1) { *nslab = nblocks; return TEM_OK; }
-  if (mode == 2) { if (name) snprintf(name, name_len, "wino_bww_k<%d, 2, %s>", CI, pair ? "true" : "false"); return TEM_OK; }
+  if (mode == 2) { if (name) snprintf(name, name_len, "wino_bww_k<%d, %d, 2, %s>", CI, CO, pair ? "true" : "false"); return TEM_OK; }
   if (!a->slabs || a->nslab != nblocks || a->accumulate) return TEM_EINVAL;
   p.magicBX = magic_for(p.BX); p.magicE = magic_for(p.E);
   p.slabs = a->slabs; p.slab_stride = a->slab_stride ? a->slab_stride : (int64_t)27 * CI * dy.C;
@@ -390,8 +438,8 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
   if (p.dbg & 8)
     fprintf(stderr, "wino_bww<%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI,
             p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
-  static bool attr[3] = {false, false, false};
-  auto go = [&](auto kern, int variant) -> int {
+  static bool attr[6] = {false, false, false, false, false, false};
+  auto go = [&](auto kern) -> int {
     if (!attr[variant]) {
       hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_B);
       if (e != hipSuccess) return (int)e;
@@ -401,9 +449,14 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
     TEM_CHECK_LAUNCH();
     return TEM_OK;
   };
-  if (pair) return go(wino_bww_k<8, 2, true>, 0);
-  if (CI == 16) return go(wino_bww_k<16, 2, false>, 1);
-  return go(wino_bww_k<8, 2, false>, 2);
+  switch (variant) {
+    case 0: return go(wino_bww_k<8, 8, 2, true>);
+    case 1: return go(wino_bww_k<16, 16, 2, false>);
+    case 2: return go(wino_bww_k<8, 16, 2, false>);
+    case 3: return go(wino_bww_k<16, 32, 2, false>);
+    case 4: return go(wino_bww_k<32, 16, 2, false>);
+    default: return go(wino_bww_k<32, 32, 2, false>);
+  }
 }
 
 }  // namespace wino

@@ -275,8 +275,10 @@ def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=
     a.pd, a.ph, a.pw = _p3(p, is3d)
     namebuf = C.create_string_buffer(96)
     if wino and not bf16 and is3d and k == 3 and s == 1 and \
-            (a.in0.C + (a.in1.C if in1 is not None else 0), dout.shape[4]) in ((16, 16), (8, 8), (8, 16)):
-        # Winograd-domain kernel gradient (ordinary slabs, one per workgroup): g.f1, g.d1a, g.d2a, d.hack
+            (a.in0.C + (a.in1.C if in1 is not None else 0), dout.shape[4]) in ((16, 16), (8, 8), (8, 16), (16, 32), (32, 16), (32, 32)) \
+            and dout.shape[1] * dout.shape[2] * dout.shape[3] >= WINO_MIN_VOXELS:
+        # Winograd-domain kernel gradient (ordinary slabs, one per workgroup) for every 3x3x3 layer with 8..32 channels
+        # on both sides above ~30^3 voxels
         a.nslab = MAX_SLABS
         nw = lib.tem_conv_bwd_weight_winograd_nslab(C.byref(a), namebuf, 96)
         if nw > 0:
