@@ -34,6 +34,9 @@ FWD_CASES = [  # (CI, CO, k, s, pad, edge, is3d)
     (16, 16, 3, 1, 0, 11, True), (16, 1, 3, 1, 0, 14, True), (32, 32, 1, 1, 0, 5, True), (32, 1, 1, 1, 0, 5, True),
     (32, 32, 4, 2, 0, 10, True), (1, 8, 3, 1, 5, 10, True), (1, 16, 3, 1, 0, 30, False), (16, 32, 3, 1, 0, 20, False),
     (32, 32, 4, 2, 0, 21, False),
+    # split-K k4 s2 kernel (conv_s2_k): padded / cropped-cone geometries, planes of fewer than 16 voxels, partial last tiles
+    (8, 16, 4, 2, 1, 14, True), (16, 32, 4, 2, 1, 11, True), (8, 8, 4, 2, 3, 12, True), (32, 32, 4, 2, 0, 8, True),
+    (16, 16, 4, 2, 0, 36, True),
     # row-blocked direct kernel (conv_rows_k: output height >= 16, not a multiple of its 4-row block)
     (16, 1, 3, 1, 0, 21, True), (8, 8, 3, 1, 2, 17, True), (1, 8, 3, 1, 0, 24, False),
 ]
@@ -169,6 +172,30 @@ def test_conv_transpose_input_gradient(H, oracle_lib, CI, CO, n):
     out = torch.empty(saved.shape, dtype=torch.float32, device="cuda")
     H.run([H.conv_launch("t", dev(g), dev(w.reshape(-1)), out, 4, 2, 1, gate=dev(saved))])
     assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+def test_conv_s2_views_and_epilogue(H, oracle_lib):
+    """conv_s2_k on cropped (strided) input / output / gate views with a skip-gradient add -- the shapes the region-restricted
+    cycle path hands it (shifted pad, windows of larger tensors)."""
+    rng = np.random.default_rng(5)
+    big = rnd(rng, 2, 20, 20, 20, 8)
+    x = big[:, 2:18, 3:19, 1:17, :]                       # 16^3 window
+    w = rnd(rng, 4, 4, 4, 8, 16) * 0.1
+    saved_big = rnd(rng, 2, 10, 10, 10, 16)
+    addt = rnd(rng, 2, 4, 4, 4, 16)
+    full = oracle_lib.conv_fwd(np.ascontiguousarray(x), w, (2, 2, 2), (1, 1, 1))          # 8^3
+    full[:, 2:6, 2:6, 2:6, :] += addt
+    ref = oracle_lib.leaky_relu_grad_from_out(full, np.ascontiguousarray(saved_big[:, 1:9, 1:9, 1:9, :]))
+    bigd, savedd = dev(big), dev(saved_big)
+    outbig = torch.zeros(2, 12, 12, 12, 16, dtype=torch.float32, device="cuda")
+    launch = H.conv_launch("t", bigd[:, 2:18, 3:19, 1:17, :], dev(w.reshape(-1)), outbig[:, 2:10, 3:11, 1:9, :], 4, 2, 1,
+                           gate=savedd[:, 1:9, 1:9, 1:9, :], add=dev(addt), add_off=2)
+    assert launch.meta["kernel"].startswith("conv_s2_k"), launch.meta["kernel"]
+    H.run([launch])
+    got = outbig.cpu().numpy()
+    assert rel_err(got[:, 2:10, 3:11, 1:9, :], ref) < TOL
+    got[:, 2:10, 3:11, 1:9, :] = 0
+    assert not got.any()                                  # nothing written outside the window
 
 
 def test_input_gradient_split_through_concat(H, oracle_lib):
