@@ -37,3 +37,8 @@ for _ in range(20): big.copy_(src)
 b.record(); torch.cuda.synchronize()
 us = a.elapsed_time(b) / 20 * 1e3
 print(f"torch copy 70 MB             {us:8.1f} us  {2 * big.numel() * 4 / us / 1e3:8.1f} GB/s")
+# C_out = 1 layers: forward g.f2 (above) and the input-gradients 8 -> 1 of the first convolutions
+gc0 = torch.randn(1, 130, 130, 130, 8, device=dev); dx = torch.empty(1, 132, 132, 132, 1, device=dev)
+l = H.conv_launch("bdc0", gc0, w, dx, 3, 1, 2, layout=H.TEM_W_FLIP_CO_CI)
+us = t([l]); nb = 4 * (8 * 130**3 + 132**3)
+print(f"{'bd.c0 8->1 @130':28s} {l.meta['kernel']:36s} {us:8.1f} us  {nb / us / 1e3:8.1f} GB/s", flush=True)

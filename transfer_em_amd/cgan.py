@@ -160,6 +160,8 @@ class _CompiledStep:
         # generators' kernel-gradient launches to two more streams (16.4 vs 15.75 ms/step -- the extra
         # LDS-bound kernels only steal CUs from the dependent chains) and HIP stream priorities for the
         # chains (17.9 ms/step).
+        # (also measured and rejected: starting the F chain a few layers behind the G chain so that one chain's
+        # full-resolution layers meet the other's 27^3..60^3 layers -- 9.74-9.77 vs 9.73 ms/step)
         main += casts + [("record", "cast")] + [flips["g"]] + L_(f_g1) + [("record", "fake_y")] + L_(f_g3) + [("wait", "fake_x")] + L_(f_g2)
         third += [("wait", "inputs"), flips["f"], ("wait", "cast")] + L_(f_f1) + [("record", "fake_x")] + L_(f_f3) + [("wait", "fake_y")] + L_(f_f2)
         main += [loss[3], loss[4]] + L_(b_g3, b_g2) + [("record", "d_fake_x")]

@@ -7,6 +7,7 @@ int tem_conv_c1_try(const tem_conv_args *a, hipStream_t st, bool dry);       // 
 int tem_convT_mfma_try(const tem_conv_args *a, hipStream_t st, bool dry);    // convT_mfma.hip
 int tem_conv_wino_try(const tem_conv_args *a, hipStream_t st, bool dry);     // wino.hip
 int tem_conv_s2_try(const tem_conv_args *a, hipStream_t st, bool dry);       // conv_s2.hip
+int tem_conv_c1out_try(const tem_conv_args *a, hipStream_t st, bool dry);    // c1out_mfma.hip
 
 extern "C" int tem_conv(const tem_conv_args *a, tem_stream_t stream) {
   TEM_CLEAR_ERR();
@@ -15,6 +16,8 @@ extern "C" int tem_conv(const tem_conv_args *a, tem_stream_t stream) {
     int rc = tem_conv_s2_try(a, (hipStream_t)stream, false);
     if (rc != TEM_EUNSUPPORTED) return rc;
     rc = tem_conv_lds_try(a, (hipStream_t)stream, false);
+    if (rc != TEM_EUNSUPPORTED) return rc;
+    rc = tem_conv_c1out_try(a, (hipStream_t)stream, false);
     if (rc != TEM_EUNSUPPORTED) return rc;
     rc = tem_conv_c1_try(a, (hipStream_t)stream, false);
     if (rc != TEM_EUNSUPPORTED) return rc;
@@ -36,6 +39,7 @@ int tem_conv_c1_describe(const tem_conv_args *a, char *buf, int len);       // s
 int tem_convT_mfma_describe(const tem_conv_args *a, char *buf, int len);    // convT_mfma.hip
 int tem_conv_wino_describe(const tem_conv_args *a, char *buf, int len);     // wino.hip
 int tem_conv_s2_describe(const tem_conv_args *a, char *buf, int len);       // conv_s2.hip
+int tem_conv_c1out_describe(const tem_conv_args *a, char *buf, int len);    // c1out_mfma.hip
 int tem_bww_lds_describe(const tem_bww_args *a, char *buf, int len);        // bww_lds.hip
 int tem_bww_c1_describe(const tem_bww_args *a, char *buf, int len);         // bww_c1.hip
 int tem_conv_direct_describe(const tem_conv_args *a, char *name, int len);  // conv_direct.hip
@@ -47,6 +51,7 @@ extern "C" int tem_conv_is_tiled(const tem_conv_args *a, int32_t transposed, cha
   if (a->w_layout == TEM_W_WINOGRAD) return tem_conv_wino_describe(a, name, name_len) == TEM_OK ? 1 : 0;
   if (tem_conv_s2_describe(a, name, name_len) == TEM_OK) return 1;
   if (tem_conv_lds_describe(a, name, name_len) == TEM_OK) return 1;
+  if (tem_conv_c1out_describe(a, name, name_len) == TEM_OK) return 1;
   if (tem_conv_c1_describe(a, name, name_len) == TEM_OK) return 1;
   if (name && name_len > 0) tem_conv_direct_describe(a, name, name_len);   // name of the direct kernel that will run
   return 0;
