@@ -166,8 +166,11 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
         kern = f"convT_direct_k<{ci0}, {co0}, {co1}, {8 if co0 + co1 == 32 else co0 + co1}>"
     else:
         kern = f"conv_direct_k<{ci0}, {ci1}, {co0}, {co1}, {'true' if a.w_layout == TEM_W_FLIP_CO_CI else 'false'}>"
+    # algorithmic bytes of the fused operator: input, output, kernel, plus the tensors its epilogue has to read (the saved
+    # activation behind a LeakyReLU-gradient gate, a skip-gradient window)
+    ep_bytes = (esz * co0 * vout if gate is not None else 0.0) + (esz * add.numel() if add is not None else 0.0)
     meta = dict(flops=2.0 * ntap * ci * co * (vin if transposed else vout),
-                bytes=esz * (ci * vin + co * vout) + 4.0 * ntap * ci * co, kernel=kern,
+                bytes=esz * (ci * vin + co * vout) + 4.0 * ntap * ci * co + ep_bytes, kernel=kern,
                 shape=f"{ci0}+{ci1}@{tuple(in0.shape[:4])} -> {co0}+{co1}@{tuple(out0.shape[:4])} k{k} s{s} p{p}")
     return Launch(fn, (C.byref(a),), name, keep + [a], meta)
 
