@@ -1,0 +1,250 @@
+// bww_s2.hip -- kernel gradient of the k4 s2 convolutions (Conv3DBackpropFilter of models/utils.py:80 and, with input and
+// gradient swapped, of the Conv3DTranspose layers, models/utils.py:129-130) on the fp32 matrix cores, fragments
+// straight from HBM/L2:
+//
+//   dW[(kz,ky,kx)][ci][co] = sum_v X[2 v + k - P][ci] * dY[v][co]
+//
+// as D[co][(tap, ci)] += A[co][v] * B[v][(tap, ci)] with the OUTPUT VOXELS as the reduction index of
+// v_mfma_f32_16x16x4_f32 (a k-step = 4 x-consecutive voxels):
+//   A: lane (co, voxel kq) reads dY[v][co] -- the 16 lanes of a voxel are one contiguous run;
+//   B: for a row tap (kz, ky) the 4 x-taps of a voxel are ONE contiguous run of 4 C_in floats of X.  The assignment of
+//      matrix columns to lanes is free, so lane n takes floats 4 n .. 4 n + 3 of that run (C_in 8: 2 n, 2 n + 1) as the
+//      columns of four (two) n-tiles: ONE 16-byte (8-byte) load per lane feeds four (two) MFMAs per m-tile -- no LDS
+//      image, no transposition, 5-6 loads per 8-32 MFMAs.
+// A workgroup owns (a range of output rows, one kz): its 4 waves take the rows of the range in turn (all four ky taps
+// each, C_in x ceil(C_out / 16) accumulator tiles per wave; a ring of 8 fragment sets keeps 7 k-steps of loads in flight), add
+// their accumulators through LDS in wave order at
+// the end and write the kz slice of ONE ordinary slab [tap][ci][co] per row range (deterministic; the four kz
+// workgroups of a range fill its slab) -- 64-128 slabs per launch.
+// Measured stand-alone (132^3 step shapes): g.bww.u2b 16 -> 32: 43.6 -> 22.8 us, g.bww.d2b 16 -> 16: 24.1 -> 19.2 us,
+// g.bww.u1b 8 -> 16: 44.2 -> 42.5 us (cone 24.9 -> 20.8) against bww_lds_k.
+#include "tem_common.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace bwws2 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct Dev {
+  const float *in;
+  int32_t iN, iD, iH, iW, D, H, W, in_bytes;
+  const float *g;
+  int32_t gN, gD, gH, gW, OD, OH, OW, g_bytes;
+  int32_t P;
+  int32_t rows, R;                                  // output rows (n, oz, oy), row ranges (= slabs)
+  uint32_t magicOH, magicOD;
+  float *slabs;
+  int64_t slab_stride;
+};
+
+constexpr int OOB = (int)0x80000000;
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t v, uint32_t d, uint32_t magic) { return d == 1 ? v : __umulhi(v, magic); }
+
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
+  constexpr int MT = (CO + 15) / 16;                // m-tiles (16 output channels each)
+  constexpr int J = CI / 4;                         // n-tiles per row tap = floats per lane of its load (16 -> 4, 8 -> 2)
+  constexpr int NACC = 4 * J * MT;                  // accumulator tiles per wave: (ky, j, mt)
+  constexpr int NBUF = 8;                           // fragment sets in flight
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int kz = blockIdx.y;
+  const int ra = (int)(((long long)blockIdx.x * p.rows) / p.R), rb = (int)(((long long)(blockIdx.x + 1) * p.rows) / p.R);
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)p.g, 0, p.g_bytes, 0x00020000);
+
+  f32x4 acc[4][J][MT];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[ky][j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the lane's floats of a row tap's run: floats J n .. J n + J - 1 = input voxel 2 ox - P + (J n) / C_in, channels (J n) % C_in ..
+  const int bvox = (J * n) / CI, bci = (J * n) & (CI - 1);
+
+  struct Frag { float a[MT]; float b[4][J]; };
+  int irow = ra + wave, iox0 = 0;                   // issue position: (row, first voxel of the k-step)
+  // Every load is issued unconditionally (one schedule for the compiler's vmcnt bookkeeping); lanes / steps with nothing to
+  // read send an out-of-range offset and receive zeros, which add nothing.
+  auto issue = [&](Frag &f) {
+    const bool live = irow < rb;
+    const int rowc = live ? irow : ra;
+    const int t = (int)fdiv((uint32_t)rowc, (uint32_t)p.OH, p.magicOH), oy = rowc - t * p.OH;   // t = nb * OD + oz
+    const int nb = (int)fdiv((uint32_t)t, (uint32_t)p.OD, p.magicOD), oz = t - nb * p.OD;
+    const int ox = iox0 + q;
+    const bool okx = live && ox < p.OW;
+    const int gbase = (nb * p.gN + oz * p.gD + oy * p.gH + ox * p.gW) * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = 16 * mt + n;
+      int goff = (okx && co < CO) ? gbase + co * 4 : OOB;
+      asm volatile("" : "+v"(goff));                  // (opaque: the compiler would otherwise split the load into two exec-masked ones)
+      f.a[mt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grs, goff, 0, 0));
+    }
+    const int iz = 2 * oz + kz - p.P, x = 2 * ox - p.P + bvox;
+    const bool okb = okx && (unsigned)iz < (unsigned)p.D && (unsigned)x < (unsigned)p.W;
+    const int xbase = (nb * p.iN + iz * p.iD + x * p.iW + bci) * 4;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int iy = 2 * oy + ky - p.P;
+      int off = (okb && (unsigned)iy < (unsigned)p.H) ? xbase + iy * p.iH * 4 : OOB;
+      asm volatile("" : "+v"(off));
+      if constexpr (J == 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+        f.b[ky][0] = __uint_as_float(v.x); f.b[ky][1] = __uint_as_float(v.y);
+        f.b[ky][2] = __uint_as_float(v.z); f.b[ky][3] = __uint_as_float(v.w);
+      } else {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, 0, 0);
+        f.b[ky][0] = __uint_as_float(v.x); f.b[ky][1] = __uint_as_float(v.y);
+      }
+    }
+    iox0 += 4;
+    if (iox0 >= p.OW) { iox0 = 0; irow += 4; }
+  };
+  auto consume = [&](const Frag &f) {
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[ky][j][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[mt], f.b[ky][j], acc[ky][j][mt], 0, 0, 0);
+  };
+
+  // k-steps of this wave: its rows (ra + wave, + 4, ...) x ceil(OW / 4).  A k-step is only 8-32 MFMAs (0.1-0.4 us) while a
+  // load takes 1-2 us to arrive: a ring of NBUF fragment sets keeps NBUF - 1 k-steps of loads in flight (5-6 VGPR-light
+  // loads each; static ring indices, no copies).
+  const int nrow_w = rb > ra + wave ? (rb - ra - wave + 3) >> 2 : 0;
+  const int total = nrow_w * ((p.OW + 3) >> 2);
+  Frag f[NBUF];
+#pragma unroll
+  for (int u = 0; u < NBUF; ++u) issue(f[u]);
+  for (int t = 0; t < total; t += NBUF) {
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) {
+      if (t + u < total) consume(f[u]);             // (wave-uniform; past the end the sets hold zeros anyway)
+      issue(f[u]);
+    }
+  }
+
+  // ---- sum over the waves through LDS (fixed order), then the kz slice of the range's slab:
+  //   part[wave][tile (ky, j, mt)][lane] (16 bytes each)
+  f32x4 *const part = reinterpret_cast<f32x4 *>(lds);
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) part[(wave * NACC + (ky * J + j) * MT + mt) * 64 + lane] = acc[ky][j][mt];
+  __syncthreads();
+  float *const slab = p.slabs + (size_t)blockIdx.x * p.slab_stride;
+  constexpr int TPW = NACC / 4;                     // tiles finished by each wave
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int tl = wave * TPW + i;                  // (wave-uniform)
+    const int mt = tl % MT, kj = tl / MT, j = kj % J, ky = kj / J;
+    f32x4 s = part[tl * 64 + lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) {
+      const f32x4 v = part[(w2 * NACC + tl) * 64 + lane];
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    // D row = output channel 16 mt + 4 q + r (r = register), column = float J n + j of the run: x-tap, input channel
+    const int fl = J * n + j, kx = fl / CI, ci = fl & (CI - 1);
+    const int tap = (kz * 4 + ky) * 4 + kx, co = 16 * mt + 4 * q;
+    if (co < CO) *reinterpret_cast<f32x4 *>(slab + (size_t)(tap * CI + ci) * CO + co) = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static uint32_t magic_for(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
+
+static int64_t span_of(const tem_view &v) {
+  return (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH + (int64_t)(v.W - 1) * v.sW + v.C;
+}
+
+static thread_local char *g_name = nullptr;
+static thread_local int g_name_len = 0;
+
+template <int CI, int CO>
+static int run(Dev p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
+  constexpr int MT = (CO + 15) / 16, J = CI / 4, NACC = 4 * J * MT;
+  const size_t lds_bytes = (size_t)4 * NACC * 64 * 16;
+  // row ranges: 128 (two workgroups per CU with the four kz) where the LDS sum leaves room for two, else 64; at least ~4
+  // rows per wave
+  int R = lds_bytes <= 80 * 1024 ? 128 : 64;
+  static int rr = -1;
+  if (rr < 0) { const char *v = getenv("TEM_BWW_S2_R"); rr = v ? atoi(v) : 0; }
+  if (rr > 0) R = rr;
+  while (R > 1 && p.rows / R < 8) R >>= 1;
+  if (R > max_slabs) R = max_slabs;
+  if (R < 1) return TEM_EUNSUPPORTED;
+  p.R = R;
+  if (nslab_out) *nslab_out = R;
+  if (g_name) snprintf(g_name, g_name_len, "bww_s2_k<%d, %d>", CI, CO);
+  if (dry) return TEM_OK;
+  static bool attr = false;
+  if (!attr && lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)bww_s2_k<CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((bww_s2_k<CI, CO>), dim3((unsigned)R, 4), dim3(256), lds_bytes, st, p);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+static int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
+  const tem_view &i0 = a->in0, &g = a->dout;
+  if (a->in1.ptr) return TEM_EUNSUPPORTED;
+  if (a->kd != 4 || a->kh != 4 || a->kw != 4 || a->sd != 2 || a->sh != 2 || a->sw != 2) return TEM_EUNSUPPORTED;
+  if (a->pd != a->ph || a->ph != a->pw) return TEM_EUNSUPPORTED;
+  static int enabled = -1;
+  if (enabled < 0) { const char *v = getenv("TEM_BWW_S2"); enabled = v ? atoi(v) : 1; }
+  if (!enabled) return TEM_EUNSUPPORTED;
+  if (g.N != i0.N) return TEM_ESHAPE;
+  const int64_t ispan = span_of(i0), gspan = span_of(g);
+  if (ispan >= ((int64_t)1 << 29) || gspan >= ((int64_t)1 << 29)) return TEM_EUNSUPPORTED;   // byte offsets below 2^31
+  if (((uintptr_t)i0.ptr & 15) || i0.sW % 4 || i0.sH % 4 || i0.sD % 4 || i0.sN % 4) return TEM_EUNSUPPORTED;
+  const int64_t rows = (int64_t)g.N * g.D * g.H;
+  if (rows > (1 << 22) || g.H > 4096 || g.D > 4096) return TEM_EUNSUPPORTED;                 // range of the magic divisions
+  const int CI = i0.C, CO = g.C;
+  const int64_t stride = a->slab_stride ? a->slab_stride : (int64_t)64 * CI * CO;
+  if (!dry && (((uintptr_t)a->slabs & 15) || stride % 4)) return TEM_EUNSUPPORTED;           // 16-byte slab stores
+  Dev p{};
+  p.in = i0.ptr; p.iN = (int)i0.sN; p.iD = (int)i0.sD; p.iH = (int)i0.sH; p.iW = (int)i0.sW;
+  p.D = i0.D; p.H = i0.H; p.W = i0.W; p.in_bytes = (int)(ispan * 4);
+  p.g = g.ptr; p.gN = (int)g.sN; p.gD = (int)g.sD; p.gH = (int)g.sH; p.gW = (int)g.sW;
+  p.OD = g.D; p.OH = g.H; p.OW = g.W; p.g_bytes = (int)(gspan * 4);
+  p.P = a->pd;
+  p.rows = (int)rows;
+  p.magicOH = magic_for(g.H); p.magicOD = magic_for(g.D);
+  p.slabs = a->slabs; p.slab_stride = stride;
+  // (8 -> 8, g.d1b / d.d1b: half of every m-tile would be zeros -- 73 vs 51 us measured; left to bww_lds_k's x-shift form)
+  if (CI == 8 && CO == 16) return run<8, 16>(p, a->nslab, st, dry, nslab_out);     // g.u1b (transposed conv: input and gradient swapped)
+  if (CI == 16 && CO == 16) return run<16, 16>(p, a->nslab, st, dry, nslab_out);   // g.d2b
+  if (CI == 16 && CO == 32) return run<16, 32>(p, a->nslab, st, dry, nslab_out);   // g.u2b
+  return TEM_EUNSUPPORTED;
+}
+
+}  // namespace bwws2
+
+// Called by tem_conv_bwd_weight (conv_bww.hip) ahead of the LDS-ring kernel.
+int tem_bww_s2_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) { return bwws2::dispatch(a, st, dry, nslab_out); }
+
+int tem_bww_s2_describe(const tem_bww_args *a, char *buf, int len) {
+  bwws2::g_name = buf; bwws2::g_name_len = len;
+  int n = 0;
+  int rc = bwws2::dispatch(a, nullptr, true, &n);
+  bwws2::g_name = nullptr;
+  return rc == TEM_OK && n == a->nslab ? TEM_OK : TEM_EUNSUPPORTED;
+}

@@ -207,11 +207,13 @@ int launch_bww(const BwwDev &p, hipStream_t st) {
 
 int tem_bww_lds_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out);   // bww_lds.hip
 int tem_bww_c1_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out);    // bww_c1.hip (C_in = 1 layers)
+int tem_bww_s2_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out);    // bww_s2.hip (k4 s2 layers)
 
 extern "C" int tem_conv_bwd_weight_nslab(const tem_bww_args *a) {
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout) || a->nslab < 1) return TEM_EINVAL;
   int n = 0;
   if (tem_bww_c1_try(a, nullptr, true, &n) == TEM_OK) return n;
+  if (tem_bww_s2_try(a, nullptr, true, &n) == TEM_OK) return n;
   if (tem_bww_lds_try(a, nullptr, true, &n) == TEM_OK) return n;
   return a->nslab < 32 ? a->nslab : 32;          // global-load kernel: any split works, 32 is plenty
 }
@@ -229,6 +231,8 @@ extern "C" int tem_conv_bwd_weight(const tem_bww_args *a, tem_stream_t stream) {
       if (tem_bww_c1_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab)
         return tem_bww_c1_try(a, (hipStream_t)stream, false, nullptr);
     }
+    if (tem_bww_s2_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab)
+      return tem_bww_s2_try(a, (hipStream_t)stream, false, nullptr);
     if (tem_bww_lds_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab)
       return tem_bww_lds_try(a, (hipStream_t)stream, false, nullptr);
   }

@@ -42,6 +42,7 @@ int tem_conv_s2_describe(const tem_conv_args *a, char *buf, int len);       // c
 int tem_conv_c1out_describe(const tem_conv_args *a, char *buf, int len);    // c1out_mfma.hip
 int tem_bww_lds_describe(const tem_bww_args *a, char *buf, int len);        // bww_lds.hip
 int tem_bww_c1_describe(const tem_bww_args *a, char *buf, int len);         // bww_c1.hip
+int tem_bww_s2_describe(const tem_bww_args *a, char *buf, int len);         // bww_s2.hip
 int tem_conv_direct_describe(const tem_conv_args *a, char *name, int len);  // conv_direct.hip
 
 extern "C" int tem_conv_is_tiled(const tem_conv_args *a, int32_t transposed, char *name, int32_t name_len) {
@@ -61,5 +62,6 @@ extern "C" int tem_bww_is_tiled(const tem_bww_args *a, char *name, int32_t name_
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->dout)) return TEM_EINVAL;
   if (name && name_len > 0) name[0] = 0;
   if (tem_bww_c1_describe(a, name, name_len) == TEM_OK) return 1;
+  if (tem_bww_s2_describe(a, name, name_len) == TEM_OK) return 1;
   return tem_bww_lds_describe(a, name, name_len) == TEM_OK ? 1 : 0;
 }
