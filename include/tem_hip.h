@@ -180,7 +180,7 @@ int tem_reduce_slabs(const float *slabs, int32_t nslab, int64_t n, int64_t slab_
                      float *out, int32_t accumulate, float scale, tem_stream_t stream);
 
 /* One work item of tem_reduce_slabs_multi: out[i] = scale * sum_{s < nslab} slabs[s*stride + i]
- * for i < count (count <= 32). */
+ * for i < count (count <= 64). */
 typedef struct tem_reduce_item {
   const float *slabs;
   int64_t      stride;

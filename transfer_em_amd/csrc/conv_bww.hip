@@ -139,36 +139,37 @@ __global__ __launch_bounds__(256) void reduce_slabs_k(const float *slabs, int ns
 }
 
 // One launch finishes the split-K sums of ALL layers of a network: block b reduces items[b]
-// (<= 32 consecutive kernel entries of one layer) over that layer's slabs.  Thread = (entry
-// tid&31, slab lane tid>>5); each lane strides the slabs by 8 with 8 loads in flight, then the
-// 8 lanes are summed through LDS in a fixed order (bitwise reproducible).
+// (<= 64 consecutive kernel entries of one layer) over that layer's slabs.  Thread = (entry
+// tid&63, slab lane tid>>6: a wave reads 256 contiguous bytes of a slab); each lane strides the slabs
+// by 4 with 8 loads in flight, then the 4 lanes are summed through LDS in a fixed order (bitwise
+// reproducible).
 __global__ __launch_bounds__(256) void reduce_multi_k(const tem_reduce_item *items, float scale) {
   const tem_reduce_item it = items[blockIdx.x];
-  const int pi = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int pi = threadIdx.x & 63, sl = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
   if (pi < it.count) {
     const float *p = it.slabs + pi;
     int s = sl;
-    for (; s + 56 < it.nslab; s += 64) {                   // 8 loads in flight per lane (the sums are latency-bound)
+    for (; s + 28 < it.nslab; s += 32) {                   // 8 loads in flight per lane (the sums are latency-bound)
       s0 += p[(int64_t)s * it.stride];
-      s1 += p[(int64_t)(s + 8) * it.stride];
-      s2 += p[(int64_t)(s + 16) * it.stride];
-      s3 += p[(int64_t)(s + 24) * it.stride];
-      s4 += p[(int64_t)(s + 32) * it.stride];
-      s5 += p[(int64_t)(s + 40) * it.stride];
-      s6 += p[(int64_t)(s + 48) * it.stride];
-      s7 += p[(int64_t)(s + 56) * it.stride];
+      s1 += p[(int64_t)(s + 4) * it.stride];
+      s2 += p[(int64_t)(s + 8) * it.stride];
+      s3 += p[(int64_t)(s + 12) * it.stride];
+      s4 += p[(int64_t)(s + 16) * it.stride];
+      s5 += p[(int64_t)(s + 20) * it.stride];
+      s6 += p[(int64_t)(s + 24) * it.stride];
+      s7 += p[(int64_t)(s + 28) * it.stride];
     }
-    for (; s < it.nslab; s += 8) s0 += p[(int64_t)s * it.stride];
+    for (; s < it.nslab; s += 4) s0 += p[(int64_t)s * it.stride];
   }
   s0 += s4; s1 += s5; s2 += s6; s3 += s7;
-  __shared__ float part[8][32];
+  __shared__ float part[4][64];
   part[sl][pi] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (sl == 0 && pi < it.count) {
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v += part[k][pi];
+    for (int k = 0; k < 4; ++k) v += part[k][pi];
     it.out[pi] = v * scale;
   }
 }

@@ -242,8 +242,8 @@ class GradWorkspace:
                 for r in range(n // row):
                     items.append((t.data_ptr() + 4 * r * row, n, nsl, row, out.data_ptr() + 4 * (n // row - 1 - r) * row))
                 continue
-            for o in range(0, n, 32):
-                items.append((t.data_ptr() + 4 * o, n, nsl, min(32, n - o), out.data_ptr() + 4 * o))
+            for o in range(0, n, 64):
+                items.append((t.data_ptr() + 4 * o, n, nsl, min(64, n - o), out.data_ptr() + 4 * o))
         arr = (_lib.tem_reduce_item * len(items))(*[_lib.tem_reduce_item(*it) for it in items])
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         table = host.to(self.params.theta.device)
