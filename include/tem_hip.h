@@ -225,6 +225,13 @@ int tem_adam_keras(float *theta, const float *grad, float *m, float *v, int64_t 
 /* *step_dev += 1 (one thread). */
 int tem_step_tick(uint32_t *step_dev, tem_stream_t stream);
 
+/* Keep bits of (up to two) Dropout(0.5) layers (models/utils.py:134) for one step, written ahead of the transposed
+ * convolutions that apply them: bit e of mask = keep(element e) of the Philox4x32-10 stream (seed, site, step) that
+ * tem_epilogue.dropout draws from -- the layout tem_epilogue.keep_mask (keep_mode 2) reads.  nbytes = ceil(elements / 128)
+ * * 16 (whole Philox blocks; 16-byte aligned); mask1 may be NULL.  step_dev (device counter) overrides step when non-NULL. */
+int tem_dropout_masks(uint8_t *mask0, int64_t nbytes0, uint32_t site0, uint8_t *mask1, int64_t nbytes1, uint32_t site1,
+                      uint64_t seed, const uint32_t *step_dev, uint32_t step, tem_stream_t stream);
+
 /* datasets.py:193-202 + 157-163: out = ((float)in / 127.5 - 1 - mean) / std */
 int tem_u8_to_f32_std(const uint8_t *in, float *out, int64_t n, float mean, float std,
                       tem_stream_t stream);

@@ -162,6 +162,19 @@ def test_dropout_keep_mask_written_forward_read_backward(H, oracle_lib):
         assert (res[0][0] == 0).mean() > 0.45
 
 
+def test_dropout_masks_launch_matches_philox_stream(H, oracle_lib):
+    """tem_dropout_masks (one launch, two Dropout layers, device step counter) writes exactly the keep bits the fused
+    epilogue draws -- the oracle's Philox4x32-10 stream (seed, site, step) over the dense element index."""
+    shapes = ((1, 6, 6, 6, 16), (1, 10, 10, 10, 8))
+    masks = [torch.zeros((int(np.prod(sh)) // 8 + 15) // 16 * 16, dtype=torch.uint8, device="cuda") for sh in shapes]
+    step = torch.tensor([7], dtype=torch.int32, device="cuda")
+    H.run([H.dropout_masks_launch("t", masks, 42, [4, 5], step)])
+    for m, sh, site in zip(masks, shapes, (4, 5)):
+        keep = oracle_lib.dropout_mask(sh, 42, site, 7).reshape(-1)
+        bits = np.unpackbits(m.cpu().numpy(), bitorder="little")[:keep.size].astype(bool)
+        assert np.array_equal(bits, keep)
+
+
 @pytest.mark.parametrize("CI,CO,n", [(32, 16, 6), (16, 8, 7)])
 def test_conv_transpose_input_gradient(H, oracle_lib, CI, CO, n):
     rng = np.random.default_rng(CO)

@@ -97,6 +97,8 @@ _SIGS = {
     "tem_adam_keras": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                        C.c_float, C.c_float, C.c_void_p, C.c_void_p],
     "tem_step_tick": [C.c_void_p, C.c_void_p],
+    "tem_dropout_masks": [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_int64, C.c_uint32, C.c_uint64, C.c_void_p,
+                          C.c_uint32, C.c_void_p],
     "tem_u8_to_f32_std": [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p],
     "tem_f32_unstd_to_u8": [_VP, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p],
     "tem_u8_tiles_to_f32_std": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

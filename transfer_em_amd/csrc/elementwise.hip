@@ -414,6 +414,33 @@ extern "C" int tem_adam_keras(float *theta, const float *grad, float *m, float *
   return TEM_OK;
 }
 
+// Keep bits of up to two Dropout layers for one step: mask bit e = DropoutStream::bit of dense element e, i.e. the 16
+// bytes of 128-element block b ARE the four Philox words of that block (little-endian) -- one 16-byte store per thread.
+__global__ __launch_bounds__(256) void dropout_masks_k(uint4 *m0, int64_t nblk0, uint32_t site0, uint4 *m1, int64_t nblk1,
+                                                       uint32_t site1, uint32_t k0, uint32_t k1, const uint32_t *step_dev,
+                                                       uint32_t step) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nblk0 + nblk1) return;
+  const bool second = i >= nblk0;
+  const int64_t b = second ? i - nblk0 : i;
+  DropoutStream ds{k0, k1, second ? site1 : site0, step_dev ? *step_dev : step};
+  const Philox128 ph = ds.block((uint64_t)b);
+  (second ? m1 : m0)[b] = make_uint4(ph.r[0], ph.r[1], ph.r[2], ph.r[3]);
+}
+
+extern "C" int tem_dropout_masks(uint8_t *mask0, int64_t nbytes0, uint32_t site0, uint8_t *mask1, int64_t nbytes1,
+                                 uint32_t site1, uint64_t seed, const uint32_t *step_dev, uint32_t step,
+                                 tem_stream_t stream) {
+  TEM_CLEAR_ERR();
+  if (!mask0 || nbytes0 <= 0 || nbytes0 % 16 || ((uintptr_t)mask0 & 15)) return TEM_EINVAL;
+  if (mask1 && (nbytes1 <= 0 || nbytes1 % 16 || ((uintptr_t)mask1 & 15))) return TEM_EINVAL;
+  const int64_t n0 = nbytes0 / 16, n1 = mask1 ? nbytes1 / 16 : 0;
+  hipLaunchKernelGGL(dropout_masks_k, dim3((unsigned)((n0 + n1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (uint4 *)mask0, n0, site0, (uint4 *)mask1, n1, site1, (uint32_t)seed, (uint32_t)(seed >> 32), step_dev, step);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
 extern "C" int tem_step_tick(uint32_t *step_dev, tem_stream_t stream) {
   TEM_CLEAR_ERR();
   if (!step_dev) return TEM_EINVAL;

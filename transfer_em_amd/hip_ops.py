@@ -370,6 +370,18 @@ def step_tick_launch(step_dev):
     return Launch(lib.tem_step_tick, (step_dev.data_ptr(),), "step_tick", [step_dev])
 
 
+def dropout_masks_launch(name, masks, seed, sites, step_dev):
+    """Keep bits of one or two Dropout layers for this step (tem_dropout_masks): `masks` are uint8 tensors of whole
+    Philox blocks (16 bytes per 128 elements), `sites` their stream sites."""
+    lib = _lib.load()
+    assert 1 <= len(masks) <= 2 and all(m.dtype == torch.uint8 and m.numel() % 16 == 0 for m in masks)
+    m1 = masks[1] if len(masks) > 1 else None
+    return Launch(lib.tem_dropout_masks,
+                  (masks[0].data_ptr(), masks[0].numel(), sites[0], m1.data_ptr() if m1 is not None else None,
+                   m1.numel() if m1 is not None else 0, sites[1] if m1 is not None else 0, seed, step_dev.data_ptr(), 0),
+                  name, list(masks) + [step_dev], dict(kernel="dropout_masks_k"))
+
+
 def fill_launch(name, t, value=0.0):
     lib = _lib.load()
     assert t.is_contiguous()

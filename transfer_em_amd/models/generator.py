@@ -173,8 +173,12 @@ class GenForward:
         if training and drop:
             for blk, layer in ((0, "u2b"), (1, "u1b")):
                 vox = N * (e[layer] if is3d else 1) * e[layer] * e[layer]
-                self.keep[blk] = torch.zeros(vox * ch[layer] // 8, dtype=torch.uint8, device=x.device)
-        km = lambda blk, mode: (self.keep[blk], mode) if blk in self.keep else None
+                nbytes = (vox * ch[layer] // 8 + 15) // 16 * 16        # whole Philox blocks (128 elements = 16 bytes)
+                self.keep[blk] = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
+        # fp32 3-D: ONE small launch per call draws both layers' keep bits ahead of the transposed convolutions, which
+        # then read them like the input-gradient kernels do (the Philox rounds cost g.u1b 10 of its 50 us)
+        premask = bool(self.keep) and is3d and not bf and not direct
+        km = lambda blk, mode: (self.keep[blk], 2 if (premask and mode == 1) else mode) if blk in self.keep else None
         kw = dict(is3d=is3d, direct=direct)
         pc = lambda p, s, i, o: p + lo(i) - s * lo(o) if i else p - s * lo(o)      # conv-like pad ('' = full input x)
         pt = lambda p, s, i, o: p + lo(o) - s * lo(i)                               # transposed-conv pad
@@ -186,6 +190,9 @@ class GenForward:
                                                           # (the train step does it once per network instead)
         wu = (lambda name: None) if (bf or direct) else P.u
         cv = H.conv_launch
+        if premask:
+            L.append(H.dropout_masks_launch("g.dropout_masks", [self.keep[0], self.keep[1]], drop[0],
+                                            [dropout_site(drop[1], 0), dropout_site(drop[1], 1)], drop[2]))
         L.append(cv("g.c0", x, wf("c0"), A["c0"], 3, 1, pc(in_pad, 1, "", "c0"), slope=H.LEAKY, **kw))
         L.append(cv("g.d1a", A["c0"], wf("d1a"), A["d1a"], 3, 1, pc(0, 1, "c0", "d1a"), slope=H.LEAKY, wino=wu("d1a"), **kw))
         L.append(cv("g.d1b", A["d1a"], wf("d1b"), A["d1b"], 4, 2, pc(0, 2, "d1a", "d1b"), slope=H.LEAKY, **kw))
