@@ -155,9 +155,14 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // The gradient voxels come through a buffer descriptor over this sample's dY: a voxel that does not exist (tile over-hang,
+  // plane past the tensor) is an out-of-range offset and arrives as zero.  [As plain loads with a select on the VALUE
+  // (`ok ? v : 0`) every load was followed by s_waitcnt vmcnt(0) -- the select sits right behind it -- i.e. 16 serialized
+  // HBM latencies per plane: 36 % of the kernel's time.]
+  const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)dyn, 0, ((p.OD - 1) * p.dD + (p.OH - 1) * p.dH + (p.OW - 1) * p.dW + CO) * 4, 0x00020000);
   auto load_dy = [&](f32x2 (&g)[JW][4], int oz) {            // the lane's 2x2 gradient voxels of its 2 JW tiles, plane oz
     const bool zok = oz + (PAIR ? (m >> 3) : 0) < p.OD;      // (PAIR: plane oz + column block)
-    const float *const base = dyn + (zok ? oz : 0) * p.dD;
 #pragma unroll
     for (int j = 0; j < JW; ++j)
 #pragma unroll
@@ -165,9 +170,11 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
 #pragma unroll
         for (int o4 = 0; o4 < 4; ++o4) {
           const bool ok = zok && ((dyok >> (8 * j + 4 * i + o4)) & 1u);
-          const float v = base[ok ? dybase[j] + (o4 >> 1) * p.dH + (2 * i + (o4 & 1)) * p.dW : 0];
-          if (i) g[j][o4].y = ok ? v : 0.f;
-          else g[j][o4].x = ok ? v : 0.f;
+          int off = ok ? (oz * p.dD + dybase[j] + (o4 >> 1) * p.dH + (2 * i + (o4 & 1)) * p.dW) * 4 : (int)0x80000000;
+          asm volatile("" : "+v"(off));                      // (opaque: one load, not two exec-masked ones)
+          const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dyrs, off, 0, 0));
+          if (i) g[j][o4].y = v;
+          else g[j][o4].x = v;
         }
   };
   __syncthreads();
@@ -175,15 +182,16 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   // The point half ph is wave-uniform; the loop body is compiled once per value (static row indices: no selects).
   auto load_dy_pair = [&](f32x2 (&g)[4], int oz, int j) {    // ... of tile pair j only
     const bool zok = oz + (PAIR ? (m >> 3) : 0) < p.OD;
-    const float *const base = dyn + (zok ? oz : 0) * p.dD;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int o4 = 0; o4 < 4; ++o4) {
         const bool ok = zok && ((dyok >> (8 * j + 4 * i + o4)) & 1u);
-        const float v = base[ok ? dybase[j] + (o4 >> 1) * p.dH + (2 * i + (o4 & 1)) * p.dW : 0];
-        if (i) g[o4].y = ok ? v : 0.f;
-        else g[o4].x = ok ? v : 0.f;
+        int off = ok ? (oz * p.dD + dybase[j] + (o4 >> 1) * p.dH + (2 * i + (o4 & 1)) * p.dW) * 4 : (int)0x80000000;
+        asm volatile("" : "+v"(off));
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dyrs, off, 0, 0));
+        if (i) g[o4].y = v;
+        else g[o4].x = v;
       }
   };
   auto run = [&](auto phc) {
@@ -414,6 +422,8 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
   p.N = i0.N; p.D = i0.D; p.H = i0.H; p.W = i0.W;
   p.span0 = (int)(((int64_t)(i0.H - 1) * p.i0H + (int64_t)(i0.W - 1) * p.i0W + i0.C) * 4);
   p.span1 = a->in1.ptr ? (int)(((int64_t)(i0.H - 1) * p.i1H + (int64_t)(i0.W - 1) * p.i1W + a->in1.C) * 4) : p.span0;
+  if (((int64_t)(dy.D - 1) * dy.sD + (int64_t)(dy.H - 1) * dy.sH + (int64_t)(dy.W - 1) * dy.sW + dy.C) >= ((int64_t)1 << 29))
+    return TEM_EUNSUPPORTED;                                 // byte offsets of the gradient's buffer loads stay below 2^31
   p.dy = dy.ptr; p.dN = (int)dy.sN; p.dD = (int)dy.sD; p.dH = (int)dy.sH; p.dW = (int)dy.sW;
   p.OD = dy.D; p.OH = dy.H; p.OW = dy.W;
   p.NTZ = (p.OD + 1) / 2;
