@@ -196,10 +196,12 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   };
   auto run = [&](auto phc) {
     constexpr int PH = decltype(phc)::value;
-    f32x2 gcur[PREF ? JW : 1][4], gnext[PREF ? JW : 1][4];   // 2x2 gradient voxels of the lane's tile pairs (k-steps 2 j, 2 j + 1)
-    if constexpr (PREF) {
-      if (nsteps > 0) load_dy(gcur, 2 * tz0);
-    }
+    // 2x2 gradient voxels of the lane's tile pairs (k-steps 2 j, 2 j + 1): two register sets used in turn, the set of the
+    // NEXT plane (PREF) / tile pair (!PREF) is in flight under the current one's MFMAs -- every load is issued
+    // unconditionally (a plane past the run is out of range and moves nothing) and never copied, so the only waits are the
+    // counted ones in front of the consuming blocks
+    f32x2 gA[PREF ? JW : 1][4], gB[PREF ? JW : 1][4];
+    if constexpr (PREF) load_dy(gA, nsteps > 0 ? 2 * tz0 : p.OD);
     for (int step = 0; step < nsteps; ++step) {
       const int tz = tz0 + step, izb = 2 * tz - p.P;
       const bool more = step + 1 < nsteps;
@@ -253,32 +255,42 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
           acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[pt >> 2][pt & 3].y, zv[pt >> 2][pt & 3].y, acc[mt][pt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);               // one tile pair's raw rows in flight at a time (register budget)
       };
+      const int oz_next = more ? 2 * tz + 2 : p.OD;          // first plane of the next step (or none)
+      if constexpr (PREF && !PAIR) {
+        load_dy(gB, 2 * tz + 1);
 #pragma unroll
-      for (int zo = 0; zo < NZO; ++zo) {
-        if constexpr (PREF) {
-          // the gradient voxels of the next output plane (next zo / next step) are fetched under this plane's MFMAs
-          if (!(p.dbg & 512)) {
-            if (!PAIR && zo == 0) load_dy(gnext, 2 * tz + 1);
-            else if (more) load_dy(gnext, 2 * tz + 2);
-          }
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+          for (int j = 0; j < JW; ++j) block(0, mt, j, gA[j]);
+        load_dy(gA, oz_next);
 #pragma unroll
-            for (int j = 0; j < JW; ++j) block(zo, mt, j, gcur[j]);
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int jj = 0; jj < JW; ++jj)
+          for (int j = 0; j < JW; ++j) block(1, mt, j, gB[j]);
+      } else if constexpr (PREF) {                           // plane pairs: one set per step, copied (16 registers)
+        load_dy(gB, oz_next);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gcur[jj][i] = gnext[jj][i];
-        } else {
-          // four tile pairs per wave: pair-major order, the gradient voxels of pair j + 1 fetched under pair j's three taps
-          load_dy_pair(gcur[0], 2 * tz + zo, 0);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < JW; ++j) block(0, mt, j, gA[j]);
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gA[jj][i] = gB[jj][i];
+      } else {
+        // four tile pairs per wave: pair-major order, the gradient voxels of pair j + 1 fetched under pair j's three taps
+        // (fetching the next plane's first pair under the last pair as well costs these register-bound variants 28-78
+        // spilled VGPRs: measured, not kept)
+#pragma unroll
+        for (int zo = 0; zo < NZO; ++zo) {
+          load_dy_pair(gA[0], 2 * tz + zo, 0);
 #pragma unroll
           for (int j = 0; j < JW; ++j) {
-            if (j + 1 < JW) load_dy_pair(gnext[0], 2 * tz + zo, j + 1);
+            if (j + 1 < JW) load_dy_pair(gB[0], 2 * tz + zo, j + 1);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) block(zo, mt, j, gcur[0]);
+            for (int mt = 0; mt < MT; ++mt) block(zo, mt, j, gA[0]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gcur[0][i] = gnext[0][i];
+            for (int i = 0; i < 4; ++i) gA[0][i] = gB[0][i];
           }
         }
       }
