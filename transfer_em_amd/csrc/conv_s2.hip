@@ -19,7 +19,8 @@
 // Tiles are 16 consecutive output voxels of one plane, linearised over (oy, ox).  One workgroup per resident slot; the
 // workgroups of an XCD walk that XCD's contiguous eighth of the tiles interleaved (see the kernel).
 // Measured stand-alone (132^3 step shapes, warm): 462 us for the eleven k4 s2 launches on the previous kernels
-// (conv_direct_k / conv_lds_k), 254 us here; e.g. input-gradient of g.u1b 60 -> 29 us (71 TFLOP/s), d.d2b 64 -> 25 us.
+// (conv_direct_k / conv_lds_k), 216 us here; e.g. input-gradient of g.u1b 60 -> 29 us (71 TFLOP/s), d.d2b 64 -> 25 us,
+// g.d1b (8 -> 8, two-block form below) 56 -> 34 us.
 #include "tem_common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +44,7 @@ struct Dev {
   float *out;
   int32_t oN, oD, oH, oW, OD, OH, OW, CO, oN_count;
   int32_t P;
+  int32_t RL;                                       // slots per output row: OW (TB: OW + 1 input voxel pairs)
   int32_t dbg;                                      // TEM_DEBUG_FLAGS (perf triage): 2 no epilogue
   int32_t in_bytes;                                 // extent of the input view (bytes), the buffer descriptor's range
   int32_t tiles_pp, plane_vox, total, iters;        // tiles per output plane, voxels per plane, tiles, iterations (T tiles each)
@@ -55,13 +57,20 @@ constexpr int OOB = (int)0x80000000;                // buffer offset past every 
 
 __device__ __forceinline__ uint32_t fdiv(uint32_t v, uint32_t d, uint32_t magic) { return d == 1 ? v : __umulhi(v, magic); }
 
-template <int CI, int NT, int T>
+// TB (8 -> 8 channels, "two blocks"): with C_out = 8 half of an n-tile would be zeros.  Here a tile row is an INPUT voxel
+// pair j (x = 2 j - P, 2 j + 1 - P; 16 contiguous floats: one 16-byte load per lane and row tap, no voxel read twice) and
+// the two halves of the columns are its two uses: columns 0..7 = taps k_x 0, 1 of output voxel j, columns 8..15 = taps
+// k_x 2, 3 of output voxel j - 1.  Half the k-steps, every MFMA column useful; the epilogue adds row j's first block and
+// row j + 1's second block.  A row of the output has OW + 1 pair slots; tiles are 16 consecutive slots, 15 apart (the
+// sixteenth row only lends its second block).
+template <int CI, int NT, int T, bool TB>
 __global__ __launch_bounds__(CI / 2 * 64) void conv_s2_k(Dev p) {
   constexpr int NWAVE = CI / 2, KQ = 32 / CI;
-  constexpr int RUNF = CI;                          // floats per lane and row tap: its x-tap's channels
+  constexpr int RUNF = TB ? 4 : CI;                 // floats per lane and row tap: its x-tap's channels (TB: a quarter of the pair)
   constexpr int CPL = RUNF / 4;                     // 16-byte loads per lane and row tap
   constexpr int NA = KQ * CPL;                      // ... per lane and tile
-  constexpr int VPT = 16;                           // output voxels per tile
+  constexpr int VPT = TB ? 15 : 16;                 // output voxels (TB: new pair slots) per tile
+  static_assert(!TB || (CI == 8 && NT == 1), "two blocks: 8 -> 8 channels");
   constexpr bool PREF = CI < 32;                    // 16 waves (four per SIMD, 128 VGPRs each) hide the latency by themselves
   constexpr int TILEF = 16 * PITCH;                 // floats of one partial tile
   constexpr int IPW = T * 64 * NT / NWAVE;          // epilogue items (row of a tile, column quad) per wave
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(CI / 2 * 64) void conv_s2_k(Dev p) {
       int n, oz, t;
       decode(min(g, p.total - 1), n, oz, t);
       const int v = t * VPT + m;
-      const int oy = (int)fdiv((uint32_t)v, (uint32_t)p.OW, p.magicOW), ox = v - oy * p.OW;
+      const int oy = (int)fdiv((uint32_t)v, (uint32_t)p.RL, p.magicOW), ox = v - oy * p.RL;      // (TB: ox = pair slot j)
       const int iz = 2 * oz + kz - p.P, x0 = 2 * ox - p.P;
       const bool okv = live && g < p.total && v < p.plane_vox && (unsigned)iz < (unsigned)p.D;
       const int base = (n * p.iN + iz * p.iD) * 4;
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(CI / 2 * 64) void conv_s2_k(Dev p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int f = kq * RUNF + jj, xt = f / CI, ci = f & (CI - 1);
-        const int co = cob + nt * 16 + m, kx = xt;
+        const int co = TB ? (m & 7) : cob + nt * 16 + m, kx = TB ? xt + 2 * (m >> 3) : xt;
         const bool ok = co < p.CO && (unsigned)kx < 4u;
         B[rr * RUNF + jj][nt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
             wrs, ok ? (((((rt0 + rr) * 4 + kx) * CI + ci) * p.CO) + co) * 4 : OOB, 0, 0));
@@ -162,8 +171,8 @@ __global__ __launch_bounds__(CI / 2 * 64) void conv_s2_k(Dev p) {
   const int erem = item - ett * (64 * NT);
   const int emi = erem / (4 * NT), ecq = erem - emi * (4 * NT);
   const int ent = ecq >> 2, ecl = 4 * (ecq & 3);
-  const int ecol = cob + 4 * ecq;                                        // first of the lane's 4 output channels
-  const bool elane = lane < IPW && ecol < p.CO && !(p.dbg & 2);
+  const int ecol = TB ? 4 * (ecq & 1) : cob + 4 * ecq;                   // first of the lane's 4 output channels
+  const bool elane = lane < IPW && (TB ? (ecq < 2 && emi < 15) : ecol < p.CO) && !(p.dbg & 2);
   const Ep &ep = p.ep;
 
   // one iteration on loaded fragments: (gate / skip-gradient loads issued,) MFMA chains, partial tiles to LDS, barrier,
@@ -174,8 +183,8 @@ __global__ __launch_bounds__(CI / 2 * 64) void conv_s2_k(Dev p) {
     int en, eoz, et;
     decode(min(g, p.total - 1), en, eoz, et);
     const int ev = et * VPT + emi;
-    const int eoy = (int)fdiv((uint32_t)ev, (uint32_t)p.OW, p.magicOW), eox = ev - eoy * p.OW;
-    const bool evalid = elane && g < p.total && ev < p.plane_vox;
+    const int eoy = (int)fdiv((uint32_t)ev, (uint32_t)p.RL, p.magicOW), eox = ev - eoy * p.RL;
+    const bool evalid = elane && g < p.total && ev < p.plane_vox && eox < p.OW;
     const u32x4 gq = __builtin_amdgcn_raw_buffer_load_b128(
         grs, evalid ? (en * ep.gN + eoz * ep.gD + eoy * ep.gH + eox * ep.gW + ecol) * 4 : OOB, 0, 0);
     const int az = eoz - ep.aoz, ay = eoy - ep.aoy, ax = eox - ep.aox;
@@ -205,9 +214,9 @@ __global__ __launch_bounds__(CI / 2 * 64) void conv_s2_k(Dev p) {
                 __builtin_amdgcn_mfma_f32_16x16x4f32(av, B[k][nt], acc[tt][nt][T * NT == 1 ? (e & 1) : 0], 0, 0, 0);
         }
         if constexpr (PREF) {
-          if (e == 1 || (T == 2 && e == 3)) {
+          if (e < T) {                                // tile e's chunk i of the next iteration behind k-step e
             __builtin_amdgcn_sched_barrier(0);        // (keeps the load HERE: the scheduler would gather them into one burst)
-            an[T == 2 && e == 3 ? 1 : 0][i] = fetch(offn[T == 2 && e == 3 ? 1 : 0][i]);
+            an[e < T ? e : 0][i] = fetch(offn[e < T ? e : 0][i]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -227,12 +236,19 @@ __global__ __launch_bounds__(CI / 2 * 64) void conv_s2_k(Dev p) {
     __syncthreads();
     // ---- sum over the waves (fixed order) + epilogue
     if (evalid) {
-      const float *s = buf + (ett * NT + ent) * TILEF + emi * PITCH + ecl;
+      const float *s = buf + (ett * NT + ent) * TILEF + emi * PITCH + (TB ? ecol : ecl);
       float4 sum = *reinterpret_cast<const float4 *>(s);
 #pragma unroll
       for (int w2 = 1; w2 < NWAVE; ++w2) {
         const float4 q = *reinterpret_cast<const float4 *>(s + w2 * (T * NT * TILEF));
         sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+      }
+      if constexpr (TB) {                               // + the next row's second block (taps k_x 2, 3 of this output voxel)
+#pragma unroll
+        for (int w2 = 0; w2 < NWAVE; ++w2) {
+          const float4 q = *reinterpret_cast<const float4 *>(s + PITCH + 8 + w2 * (T * NT * TILEF));
+          sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+        }
       }
       float vv[4] = {sum.x + __uint_as_float(aq.x), sum.y + __uint_as_float(aq.y), sum.z + __uint_as_float(aq.z),
                      sum.w + __uint_as_float(aq.w)};
@@ -285,18 +301,20 @@ static bool fits32(const tem_view &v) {
 static thread_local char *g_name = nullptr;
 static thread_local int g_name_len = 0;
 
-template <int CI, int NT, int T>
+template <int CI, int NT, int T, bool TB = false>
 static int run(Dev p, hipStream_t st, bool dry) {
-  constexpr int NWAVE = CI / 2, VPT = 16;
+  constexpr int NWAVE = CI / 2, VPT = TB ? 15 : 16;
   if (dry) {
-    if (g_name) snprintf(g_name, g_name_len, "conv_s2_k<%d, %d, %d>", CI, NT, T);
+    if (g_name) snprintf(g_name, g_name_len, "conv_s2_k<%d, %d, %d, %s>", CI, NT, T, TB ? "true" : "false");
     return TEM_OK;
   }
+  p.RL = TB ? p.OW + 1 : p.OW;
+  p.plane_vox = p.OH * p.RL;
   p.tiles_pp = (p.plane_vox + VPT - 1) / VPT;
   const int64_t total = (int64_t)p.oN_count * p.OD * p.tiles_pp;
   if (total > (1 << 22) || p.tiles_pp > 1024 || p.OW > 1024) return TEM_EUNSUPPORTED;    // range of the magic divisions
   p.total = (int)total;
-  p.magicOW = magic_for(p.OW); p.magicTpp = magic_for(p.tiles_pp); p.magicOD = magic_for(p.OD);
+  p.magicOW = magic_for(p.RL); p.magicTpp = magic_for(p.tiles_pp); p.magicOD = magic_for(p.OD);
   p.iters = (p.total + T - 1) / T;
   // as many workgroups as are resident at once (each keeps its B fragment for its whole contiguous range of tiles: the
   // ~3 us prologue -- B loads, first A loads -- is paid once per CU slot; more, shorter workgroups measured 15-25 % slower)
@@ -308,11 +326,11 @@ static int run(Dev p, hipStream_t st, bool dry) {
   const size_t lds_bytes = (size_t)2 * NWAVE * T * NT * 16 * PITCH * 4;
   static bool attr = false;
   if (!attr && lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)conv_s2_k<CI, NT, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void *)conv_s2_k<CI, NT, T, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL((conv_s2_k<CI, NT, T>), dim3((unsigned)nblocks, (unsigned)ny), dim3(NWAVE * 64), lds_bytes, st, p);
+  hipLaunchKernelGGL((conv_s2_k<CI, NT, T, TB>), dim3((unsigned)nblocks, (unsigned)ny), dim3(NWAVE * 64), lds_bytes, st, p);
   TEM_CHECK_LAUNCH();
   return TEM_OK;
 }
@@ -365,7 +383,10 @@ static int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   { static int dbg = -1; if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; } p.dbg = dbg; }
   p.plane_vox = o0.H * o0.W;
   const int CI = i0.C, CO = o0.C;
-  if (CI == 8 && (CO == 8 || CO == 16)) return run<8, 1, 2>(p, st, dry);     // g.d1b, d.d1b (C_out 8: half of the n-tile is zeros; pairing x-neighbours in the columns measured no faster); input-gradient of g.u1b
+  static int tb = -1;
+  if (tb < 0) { const char *v = getenv("TEM_S2_TB"); tb = v ? atoi(v) : 1; }
+  if (tb && CI == 8 && CO == 8) return run<8, 1, 4, true>(p, st, dry);           // g.d1b, d.d1b: two-block form
+  if (CI == 8 && (CO == 8 || CO == 16)) return run<8, 1, 2>(p, st, dry);     // 8 -> 8 without the two-block form (fallback); input-gradient of g.u1b
   if (CI == 16 && CO == 16) return run<16, 1, 2>(p, st, dry);                // g.d2b
   if (CI == 16 && CO == 32) return run<16, 2, 2>(p, st, dry);                // input-gradient of g.u2b
   if (CI == 32 && CO == 32) return run<32, 1, 1>(p, st, dry);                // d.d2b, d.d3b (two workgroups per tile: one per 16 output channels)
