@@ -43,6 +43,7 @@ struct Ep {
   int32_t doz, doy, dox, dD, dH, dW;
   uint8_t *keep_mask;
   int32_t keep_mode;
+  int32_t gbytes, abytes, mbytes;                // extents (bytes) of the gate / add views and of the keep mask: buffer ranges
 };
 
 struct Dev {
@@ -161,22 +162,33 @@ __global__ __launch_bounds__(256) void convT_bf16_k(Dev p, const u16 *__restrict
   };
   // Epilogue in two halves: `prep` (before the tile's MFMA chain) computes the lane's output voxel and ISSUES the
   // gate / skip-gradient loads, `finish` (after it) consumes them -- their HBM/L2 latency hides under the matrix work.
-  struct Prep { int oy, ox; bool valid; uint2 g4, a4; };
+  // (through buffer descriptors, out-of-range = zeros: as conditional plain loads the value merge put s_waitcnt vmcnt(0) in
+  // front of the MFMA chain -- see conv_bf16.hip)
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)ep.gate, 0, ep.gate ? ep.gbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)ep.add, 0, ep.add ? ep.abytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void *)ep.keep_mask, 0, ep.keep_mode == 2 ? ep.mbytes : 0, 0x00020000);
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  struct Prep { int oy, ox; bool valid; uint2 g4, a4; uint32_t kb; };
   auto prep = [&](int t, int ry, int oz) -> Prep {
     Prep q;
     const int v = t * 16 + ti;
     const int qy = p.nQx == 1 ? v : (int)__umulhi((uint32_t)v, p.magicQx), qx = v - qy * p.nQx;
     q.oy = 2 * (Qy0 + qy) + ry - p.P; q.ox = 2 * (p.Qlo_x + qx) + erx - p.P;
     q.valid = v < L && (unsigned)q.oy < (unsigned)p.OH && (unsigned)q.ox < (unsigned)p.OW;
-    q.g4 = make_uint2(0x3f803f80u, 0x3f803f80u); q.a4 = make_uint2(0u, 0u);
-    if (q.valid) {
-      if (ep.gate) q.g4 = *reinterpret_cast<const uint2 *>(ep.gate + (n * ep.gN + oz * ep.gD + q.oy * ep.gH + q.ox * ep.gW + eco));
-      if (ep.add) {
-        const int az = oz - ep.aoz, ay = q.oy - ep.aoy, ax = q.ox - ep.aox;
-        if ((unsigned)az < (unsigned)ep.aDd && (unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw)
-          q.a4 = *reinterpret_cast<const uint2 *>(ep.add + (n * ep.aN + az * ep.aD + ay * ep.aH + ax * ep.aW + eco));
-      }
-    }
+    int goff = q.valid ? (n * ep.gN + oz * ep.gD + q.oy * ep.gH + q.ox * ep.gW + eco) * 2 : (int)0x80000000;
+    asm volatile("" : "+v"(goff));
+    const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(grs, goff, 0, 0);
+    q.g4 = make_uint2(g.x, g.y);
+    const int az = oz - ep.aoz, ay = q.oy - ep.aoy, ax = q.ox - ep.aox;
+    const bool ain = q.valid && (unsigned)az < (unsigned)ep.aDd && (unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw;
+    int aoff = ain ? (n * ep.aN + az * ep.aD + ay * ep.aH + ax * ep.aW + eco) * 2 : (int)0x80000000;
+    asm volatile("" : "+v"(aoff));
+    const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(ars, aoff, 0, 0);
+    q.a4 = make_uint2(a.x, a.y);
+    const uint32_t e3 = (uint32_t)((((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (q.oy + ep.doy)) * ep.dW + (q.ox + ep.dox)) * (uint64_t)CO + eco) >> 3);
+    int moff = q.valid ? (int)e3 : (int)0x80000000;
+    asm volatile("" : "+v"(moff));
+    q.kb = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(mrs, moff, 0, 0);
     return q;
   };
   auto finish = [&](const f32x4 &acc, const Prep &q, int oz) {
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(256) void convT_bf16_k(Dev p, const u16 *__restrict
       const uint64_t e = ((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint64_t)CO + eco;
       uint32_t bits;
       if (ep.keep_mode == 2) {
-        bits = valid ? ((uint32_t)ep.keep_mask[e >> 3] >> (uint32_t)(e & 4u)) & 15u : 0u;
+        bits = (q.kb >> (uint32_t)(e & 4u)) & 15u;              // (fetched by prep; zero for lanes without a voxel)
       } else {
         const Philox128 ph = ds.block(e >> 7);
         const uint32_t eb = (uint32_t)(e & 127);
@@ -348,6 +360,18 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   q.doz = e.drop_org[0]; q.doy = e.drop_org[1]; q.dox = e.drop_org[2];
   q.dD = e.drop_dims[0] ? e.drop_dims[0] : o0.D; q.dH = e.drop_dims[0] ? e.drop_dims[1] : o0.H;
   q.dW = e.drop_dims[0] ? e.drop_dims[2] : o0.W;
+  {
+    auto span = [](const tem_view &v) {
+      return (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH + (int64_t)(v.W - 1) * v.sW + v.C;
+    };
+    const int64_t melems = (int64_t)o0.N * q.dD * q.dH * q.dW * o0.C;
+    if (melems >= ((int64_t)1 << 33)) return TEM_EUNSUPPORTED;
+    q.mbytes = (int)((melems + 7) / 8);
+    if ((e.gate.ptr && span(e.gate) >= ((int64_t)1 << 30)) || (e.add.ptr && span(e.add) >= ((int64_t)1 << 30)))
+      return TEM_EUNSUPPORTED;                     // byte offsets of the epilogue's buffer loads stay below 2^31
+    q.gbytes = e.gate.ptr ? (int)(span(e.gate) * 2) : 0;
+    q.abytes = e.add.ptr ? (int)(span(e.add) * 2) : 0;
+  }
   const int CI = i0.C, CO = o0.C, N = i0.N;
 #define CT_CASE(ci, co, pf, ncls) if (CI == ci && CO == co) return run<ci, co, pf, ncls>(p, N, U(a->w), st, dry);
   CT_CASE(16, 8, 12, 1)     // g.u1b forward (Conv3DTranspose 16 -> 8)

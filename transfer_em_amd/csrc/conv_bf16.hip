@@ -43,6 +43,7 @@ struct Ep {
   int32_t doz, doy, dox, dD, dH, dW;
   uint8_t *keep_mask;
   int32_t keep_mode;
+  int32_t gbytes, abytes, mbytes;  // extents (bytes) of the gate / add views and of the keep mask: buffer ranges
 };
 
 struct Dev {
@@ -222,22 +223,36 @@ __global__ __launch_bounds__(256) void conv_bf16_k(Dev p) {
     }
   };
 
-  struct Prep { int oy, ox; bool valid; uint2 g, a; };
+  // (gate / skip-gradient / keep-byte loads through buffer descriptors: a lane without an output voxel, a voxel outside the
+  // skip-gradient window or an absent tensor is an out-of-range offset = zeros.  As conditional plain loads the merge of
+  // loaded value and default sat right behind the load -- s_waitcnt vmcnt(0) IN FRONT of the MFMA chain, a full memory
+  // latency per tile pair at 16x the fp32 matrix rate.)
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)ep.gate, 0, ep.gate ? ep.gbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)ep.add, 0, ep.add ? ep.abytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void *)ep.keep_mask, 0, ep.keep_mode == 2 ? ep.mbytes : 0, 0x00020000);
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  struct Prep { int oy, ox; bool valid; uint2 g, a; uint32_t kb; };
   auto prep = [&](int t) -> Prep {
     Prep q;
     const int v = t * 16 + ti;
     const int r = fdiv(v, p.TX, p.magicTX), x = v - r * p.TX;
     q.oy = oy0 + r; q.ox = ox0 + x;
     q.valid = v < L && x < TXo && eco < CO;
-    q.g = make_uint2(0x3f803f80u, 0x3f803f80u); q.a = make_uint2(0u, 0u);
-    if (q.valid && first) {
-      if (ep.gate) q.g = *reinterpret_cast<const uint2 *>(ep.gate + (n * ep.gN + oz * ep.gD + q.oy * ep.gH + q.ox * ep.gW + eco));
-      if (ep.add) {
-        const int az = oz - ep.aoz, ay = q.oy - ep.aoy, ax = q.ox - ep.aox;
-        if ((unsigned)az < (unsigned)ep.aDd && (unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw)
-          q.a = *reinterpret_cast<const uint2 *>(ep.add + (n * ep.aN + az * ep.aD + ay * ep.aH + ax * ep.aW + eco));
-      }
-    }
+    const bool vf = q.valid && first;
+    int goff = vf ? (n * ep.gN + oz * ep.gD + q.oy * ep.gH + q.ox * ep.gW + eco) * 2 : (int)0x80000000;
+    asm volatile("" : "+v"(goff));
+    const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(grs, goff, 0, 0);
+    q.g = make_uint2(g.x, g.y);
+    const int az = oz - ep.aoz, ay = q.oy - ep.aoy, ax = q.ox - ep.aox;
+    const bool ain = vf && (unsigned)az < (unsigned)ep.aDd && (unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw;
+    int aoff = ain ? (n * ep.aN + az * ep.aD + ay * ep.aH + ax * ep.aW + eco) * 2 : (int)0x80000000;
+    asm volatile("" : "+v"(aoff));
+    const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(ars, aoff, 0, 0);
+    q.a = make_uint2(a.x, a.y);
+    const uint32_t e3 = (uint32_t)((((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (q.oy + ep.doy)) * ep.dW + (q.ox + ep.dox)) * (uint64_t)p.CO0 + eco) >> 3);
+    int moff = vf ? (int)e3 : (int)0x80000000;
+    asm volatile("" : "+v"(moff));
+    q.kb = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(mrs, moff, 0, 0);
     return q;
   };
   auto finish = [&](const f32x4 &acc, const Prep &q) {
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_bf16_k(Dev p) {
         const uint64_t e = ((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint64_t)p.CO0 + eco;
         uint32_t bits;
         if (ep.keep_mode == 2) {
-          bits = valid ? ((uint32_t)ep.keep_mask[e >> 3] >> (uint32_t)(e & 4u)) & 15u : 0u;
+          bits = (q.kb >> (uint32_t)(e & 4u)) & 15u;          // (fetched by prep; zero for lanes without a voxel)
         } else {
           const Philox128 ph = ds.block(e >> 7);
           const uint32_t eb = (uint32_t)(e & 127);
@@ -456,6 +471,18 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   q.doz = e.drop_org[0]; q.doy = e.drop_org[1]; q.dox = e.drop_org[2];
   q.dD = e.drop_dims[0] ? e.drop_dims[0] : o0.D; q.dH = e.drop_dims[0] ? e.drop_dims[1] : o0.H;
   q.dW = e.drop_dims[0] ? e.drop_dims[2] : o0.W;
+  {
+    auto span = [](const tem_view &v) {
+      return (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH + (int64_t)(v.W - 1) * v.sW + v.C;
+    };
+    const int64_t melems = (int64_t)o0.N * q.dD * q.dH * q.dW * o0.C;
+    if (melems >= ((int64_t)1 << 33)) return TEM_EUNSUPPORTED;
+    q.mbytes = (int)((melems + 7) / 8);
+    if ((e.gate.ptr && span(e.gate) >= ((int64_t)1 << 30)) || (e.add.ptr && span(e.add) >= ((int64_t)1 << 30)))
+      return TEM_EUNSUPPORTED;                     // byte offsets of the epilogue's buffer loads stay below 2^31
+    q.gbytes = e.gate.ptr ? (int)(span(e.gate) * 2) : 0;
+    q.abytes = e.add.ptr ? (int)(span(e.add) * 2) : 0;
+  }
   const int K = a->kd, S = a->sd, N = i0.N;
 #define CB(ci, co, k, s, pf) if (CI == ci && CO == co && K == k && S == s) return run<ci, co, k, s, pf, true>(p, N, st, dry);
 #define CBG(ci, co, k, s, pf) if (CI == ci && CO == co && K == k && S == s) return run<ci, co, k, s, pf, false>(p, N, st, dry);
