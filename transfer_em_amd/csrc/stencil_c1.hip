@@ -358,6 +358,8 @@ __global__ __launch_bounds__(256) void c1_mfma_k(DevM p, const float *__restrict
     float a0[KS], a1[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) { a0[s] = s0[offk[s]]; a1[s] = s1[offk[s]]; }
+    __builtin_amdgcn_sched_barrier(0);                    // (all 2 KS reads in flight before the first MFMA: left alone, the
+                                                          // scheduler sinks each read next to its MFMA -- ds_read, lgkmcnt(0), MFMA)
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
