@@ -169,6 +169,12 @@ def main():
         else:
             roof = dict(bound="hbm", achieved=dom["bytes"] / secs / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # `achieved` counts ALGORITHMIC work (direct-form flops of the operator).  The Winograd-form kernels
+        # execute 2.25x fewer multiply-adds on the matrix cores for it: their hardware utilisation is reported beside it.
+        roof["flop_count"] = "algorithmic (direct-form convolution flops / launch duration)"
+        if roof["bound"] == "mfma" and dom_k.startswith("wino_"):
+            roof["executed_mfma_tflops"] = roof["achieved"] / 2.25
+            roof["executed_mfma_frac"] = roof["achieved"] / 2.25 / roof["peak"]
         # HBM bytes per launch of this kernel from the PMC passes of profiles/collect_round.sh (the counters cannot
         # be read inside this process): average over the same launches of the train step that `achieved` averages
         # over; null if the kernel has not been profiled
