@@ -16,7 +16,8 @@ def t(launches, n=20):
 tot = 0.0
 for name, ci, co, nin, p in (("g.bww.d1b 8->8 126", 8, 8, 126, 0), ("d1b cone 102", 8, 8, 102, 0), ("g.bww.u1b 8->16 100 p1", 8, 16, 100, 1),
                              ("u1b cone 64 p3", 8, 16, 64, 3), ("g.bww.d2b 16->16 60", 16, 16, 60, 0), ("g.bww.u2b 16->32 54 p1", 16, 32, 54, 1),
-                             ("u2b cone 38 p3", 16, 32, 38, 3), ("d.bww.d1b 8->8 94", 8, 8, 94, 0)):
+                             ("u2b cone 38 p3", 16, 32, 38, 3), ("d.bww.d1b 8->8 94", 8, 8, 94, 0),
+                             ("d.bww.d2b 32->32 42", 32, 32, 42, 0), ("d.bww.d3b 32->32 18", 32, 32, 18, 0)):
     torch.manual_seed(2)
     o = (nin + 2 * p - 4) // 2 + 1
     x = torch.randn(1, nin, nin, nin, ci, device=dev)

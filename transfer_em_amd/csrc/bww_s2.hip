@@ -48,7 +48,11 @@ template <int CI, int CO>
 __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
   constexpr int MT = (CO + 15) / 16;                // m-tiles (16 output channels each)
   constexpr int J = CI / 4;                         // n-tiles per row tap = floats per lane of its load (16 -> 4, 8 -> 2)
-  constexpr int NACC = 4 * J * MT;                  // accumulator tiles per wave: (ky, j, mt)
+  constexpr bool WKY = CI == 32;                    // 32 input channels: 8 n-tiles per row tap -- a wave takes ONE ky (of every
+                                                    // row of the range) instead of every fourth row with all four: its 16
+                                                    // accumulator tiles are its own taps, no sum over the waves
+  constexpr int NKY = WKY ? 1 : 4;                  // ky taps per wave
+  constexpr int NACC = NKY * J * MT;                // accumulator tiles per wave: (ky, j, mt)
   constexpr int NBUF = 8;                           // fragment sets in flight
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -60,9 +64,9 @@ __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)p.g, 0, p.g_bytes, 0x00020000);
 
-  f32x4 acc[4][J][MT];
+  f32x4 acc[NKY][J][MT];
 #pragma unroll
-  for (int ky = 0; ky < 4; ++ky)
+  for (int ky = 0; ky < NKY; ++ky)
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -71,8 +75,8 @@ __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
   // the lane's floats of a row tap's run: floats J n .. J n + J - 1 = input voxel 2 ox - P + (J n) / C_in, channels (J n) % C_in ..
   const int bvox = (J * n) / CI, bci = (J * n) & (CI - 1);
 
-  struct Frag { float a[MT]; float b[4][J]; };
-  int irow = ra + wave, iox0 = 0;                   // issue position: (row, first voxel of the k-step)
+  struct Frag { float a[MT]; float b[NKY][J]; };
+  int irow = WKY ? ra : ra + wave, iox0 = 0;                   // issue position: (row, first voxel of the k-step)
   // Every load is issued unconditionally (one schedule for the compiler's vmcnt bookkeeping); lanes / steps with nothing to
   // read send an out-of-range offset and receive zeros, which add nothing.
   auto issue = [&](Frag &f) {
@@ -94,25 +98,28 @@ __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
     const bool okb = okx && (unsigned)iz < (unsigned)p.D && (unsigned)x < (unsigned)p.W;
     const int xbase = (nb * p.iN + iz * p.iD + x * p.iW + bci) * 4;
 #pragma unroll
-    for (int ky = 0; ky < 4; ++ky) {
-      const int iy = 2 * oy + ky - p.P;
+    for (int kyi = 0; kyi < NKY; ++kyi) {
+      const int iy = 2 * oy + (WKY ? wave : kyi) - p.P;
       int off = (okb && (unsigned)iy < (unsigned)p.H) ? xbase + iy * p.iH * 4 : OOB;
       asm volatile("" : "+v"(off));
-      if constexpr (J == 4) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
-        f.b[ky][0] = __uint_as_float(v.x); f.b[ky][1] = __uint_as_float(v.y);
-        f.b[ky][2] = __uint_as_float(v.z); f.b[ky][3] = __uint_as_float(v.w);
-      } else {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, 0, 0);
-        f.b[ky][0] = __uint_as_float(v.x); f.b[ky][1] = __uint_as_float(v.y);
+#pragma unroll
+      for (int c = 0; c < J / 4 + (J < 4 ? 1 : 0); ++c) {          // 16-byte (C_in 8: 8-byte) pieces of the lane's J floats
+        if constexpr (J >= 4) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, off + 16 * c, 0, 0);
+          f.b[kyi][4 * c + 0] = __uint_as_float(v.x); f.b[kyi][4 * c + 1] = __uint_as_float(v.y);
+          f.b[kyi][4 * c + 2] = __uint_as_float(v.z); f.b[kyi][4 * c + 3] = __uint_as_float(v.w);
+        } else {
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, 0, 0);
+          f.b[kyi][0] = __uint_as_float(v.x); f.b[kyi][1] = __uint_as_float(v.y);
+        }
       }
     }
     iox0 += 4;
-    if (iox0 >= p.OW) { iox0 = 0; irow += 4; }
+    if (iox0 >= p.OW) { iox0 = 0; irow += WKY ? 1 : 4; }
   };
   auto consume = [&](const Frag &f) {
 #pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
+    for (int ky = 0; ky < NKY; ++ky)
 #pragma unroll
       for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
   // k-steps of this wave: its rows (ra + wave, + 4, ...) x ceil(OW / 4).  A k-step is only 8-32 MFMAs (0.1-0.4 us) while a
   // load takes 1-2 us to arrive: a ring of NBUF fragment sets keeps NBUF - 1 k-steps of loads in flight (5-6 VGPR-light
   // loads each; static ring indices, no copies).
-  const int nrow_w = rb > ra + wave ? (rb - ra - wave + 3) >> 2 : 0;
+  const int nrow_w = WKY ? rb - ra : (rb > ra + wave ? (rb - ra - wave + 3) >> 2 : 0);
   const int total = nrow_w * ((p.OW + 3) >> 2);
   Frag f[NBUF];
 #pragma unroll
@@ -138,9 +145,21 @@ __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
 
   // ---- sum over the waves through LDS (fixed order), then the kz slice of the range's slab:
   //   part[wave][tile (ky, j, mt)][lane] (16 bytes each)
+  float *const slab0 = p.slabs + (size_t)blockIdx.x * p.slab_stride;
+  if constexpr (WKY) {                              // the wave's own taps (kz, ky = wave): straight to the slab
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int fl = J * n + j, kx = fl / CI, ci = fl & (CI - 1);
+        const int tap = (kz * 4 + wave) * 4 + kx, co = 16 * mt + 4 * q;
+        if (co < CO) *reinterpret_cast<f32x4 *>(slab0 + (size_t)(tap * CI + ci) * CO + co) = acc[0][j][mt];
+      }
+    return;
+  }
   f32x4 *const part = reinterpret_cast<f32x4 *>(lds);
 #pragma unroll
-  for (int ky = 0; ky < 4; ++ky)
+  for (int ky = 0; ky < NKY; ++ky)
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -178,14 +197,14 @@ static thread_local int g_name_len = 0;
 template <int CI, int CO>
 static int run(Dev p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   constexpr int MT = (CO + 15) / 16, J = CI / 4, NACC = 4 * J * MT;
-  const size_t lds_bytes = (size_t)4 * NACC * 64 * 16;
+  const size_t lds_bytes = CI == 32 ? 0 : (size_t)4 * NACC * 64 * 16;
   // row ranges: 128 (two workgroups per CU with the four kz) where the LDS sum leaves room for two, else 64; at least ~4
   // rows per wave
   int R = lds_bytes <= 80 * 1024 ? 128 : 64;
   static int rr = -1;
   if (rr < 0) { const char *v = getenv("TEM_BWW_S2_R"); rr = v ? atoi(v) : 0; }
   if (rr > 0) R = rr;
-  while (R > 1 && p.rows / R < 8) R >>= 1;
+  while (R > 1 && p.rows / R < (CI == 32 ? 2 : 8)) R >>= 1;     // (32 input channels: every wave walks all rows of the range)
   if (R > max_slabs) R = max_slabs;
   if (R < 1) return TEM_EUNSUPPORTED;
   p.R = R;
@@ -233,6 +252,7 @@ static int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_
   if (CI == 8 && CO == 16) return run<8, 16>(p, a->nslab, st, dry, nslab_out);     // g.u1b (transposed conv: input and gradient swapped)
   if (CI == 16 && CO == 16) return run<16, 16>(p, a->nslab, st, dry, nslab_out);   // g.d2b
   if (CI == 16 && CO == 32) return run<16, 32>(p, a->nslab, st, dry, nslab_out);   // g.u2b
+  if (CI == 32 && CO == 32) return run<32, 32>(p, a->nslab, st, dry, nslab_out);   // d.d2b, d.d3b
   return TEM_EUNSUPPORTED;
 }
 
