@@ -7,6 +7,7 @@ is a flat list of `lib.fn(byref(args), stream)` calls -- cheap on the host and c
 into a hipGraph because no argument changes between steps (per-step scalars live in device
 memory).
 """
+import os
 import ctypes as C
 
 import torch
@@ -420,7 +421,7 @@ def wino_weights_launch(name, theta, u, table_dev, nlayers):
                   [theta, u, table_dev])
 
 
-WINO_MIN_VOXELS = 27000
+WINO_MIN_VOXELS = int(os.environ.get("TEM_WINO_MIN_VOXELS", "27000"))
 WINO_U_FLOATS = 6144          # floats of the Winograd-domain copy of one 3x3x3 kernel per 8 input and <= 16 output channels
 
 
