@@ -17,18 +17,20 @@ tot = 0.0
 for name, ci, co, nin, p in (("g.bww.d1b 8->8 126", 8, 8, 126, 0), ("d1b cone 102", 8, 8, 102, 0), ("g.bww.u1b 8->16 100 p1", 8, 16, 100, 1),
                              ("u1b cone 64 p3", 8, 16, 64, 3), ("g.bww.d2b 16->16 60", 16, 16, 60, 0), ("g.bww.u2b 16->32 54 p1", 16, 32, 54, 1),
                              ("u2b cone 38 p3", 16, 32, 38, 3), ("d.bww.d1b 8->8 94", 8, 8, 94, 0),
-                             ("d.bww.d2b 32->32 42", 32, 32, 42, 0), ("d.bww.d3b 32->32 18", 32, 32, 18, 0)):
+                             ("d.bww.d2b 32->32 42", 32, 32, 42, 0), ("d.bww.d3b 32->32 18", 32, 32, 18, 0),
+                             ("k3 g.bww.u2a 16->32 29", 16, 32, 29, 0), ("k3 d.bww.d3a 32->32 20", 32, 32, 20, 0)):
     torch.manual_seed(2)
-    o = (nin + 2 * p - 4) // 2 + 1
+    k, st = (3, 1) if name.startswith("k3") else (4, 2)
+    o = (nin + 2 * p - k) // st + 1
     x = torch.randn(1, nin, nin, nin, ci, device=dev)
     g = torch.randn(1, o, o, o, co, device=dev)
-    P = ParamSet({"w": (4, 4, 4, ci, co)}, dev, seed=1)
+    P = ParamSet({"w": (k, k, k, ci, co)}, dev, seed=1)
     ws = H.GradWorkspace(P, 1)
-    l = H.bww_launch(name, x, g, ws, "w", 0, 4, 2, p)
+    l = H.bww_launch(name, x, g, ws, "w", 0, k, st, p)
     red = ws.reduce_launches("r")
     H.run([l] + red); torch.cuda.synchronize()
     us, ur = t([l]), t(red)
     tot += us
-    fl = 2.0 * 64 * ci * co * o ** 3
+    fl = 2.0 * k ** 3 * ci * co * o ** 3
     print(f"{name:26s} {l.meta['kernel']:44s} {us:7.1f} us {fl/us/1e6:6.1f} TF/s | reduce {ur:6.1f} us", flush=True)
 print(f"sum {tot:.1f} us")

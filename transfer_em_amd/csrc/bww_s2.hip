@@ -44,14 +44,17 @@ constexpr int OOB = (int)0x80000000;
 
 __device__ __forceinline__ uint32_t fdiv(uint32_t v, uint32_t d, uint32_t magic) { return d == 1 ? v : __umulhi(v, magic); }
 
-template <int CI, int CO>
+// KS, S: kernel extent and stride -- 4, 2 (the layers this file was written for) or 3, 1 (the 3x3x3 layers under ~30^3 voxels,
+// where the Winograd-domain kernel's prologue outweighs its gain: the run of a row tap is still 4 voxels = 4 C_in floats,
+// the columns of the fourth voxel are computed and dropped).
+template <int CI, int CO, int KS, int S>
 __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
   constexpr int MT = (CO + 15) / 16;                // m-tiles (16 output channels each)
   constexpr int J = CI / 4;                         // n-tiles per row tap = floats per lane of its load (16 -> 4, 8 -> 2)
   constexpr bool WKY = CI == 32;                    // 32 input channels: 8 n-tiles per row tap -- a wave takes ONE ky (of every
                                                     // row of the range) instead of every fourth row with all four: its 16
                                                     // accumulator tiles are its own taps, no sum over the waves
-  constexpr int NKY = WKY ? 1 : 4;                  // ky taps per wave
+  constexpr int NKY = WKY ? 1 : KS;                 // ky taps per wave
   constexpr int NACC = NKY * J * MT;                // accumulator tiles per wave: (ky, j, mt)
   constexpr int NBUF = 8;                           // fragment sets in flight
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4;
   const int kz = blockIdx.y;
+  if (WKY && wave >= KS) return;                    // (k 3: the fourth wave has no ky; no barrier on this path)
   const int ra = (int)(((long long)blockIdx.x * p.rows) / p.R), rb = (int)(((long long)(blockIdx.x + 1) * p.rows) / p.R);
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
@@ -94,12 +98,12 @@ __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
       asm volatile("" : "+v"(goff));                  // (opaque: the compiler would otherwise split the load into two exec-masked ones)
       f.a[mt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grs, goff, 0, 0));
     }
-    const int iz = 2 * oz + kz - p.P, x = 2 * ox - p.P + bvox;
+    const int iz = S * oz + kz - p.P, x = S * ox - p.P + bvox;
     const bool okb = okx && (unsigned)iz < (unsigned)p.D && (unsigned)x < (unsigned)p.W;
     const int xbase = (nb * p.iN + iz * p.iD + x * p.iW + bci) * 4;
 #pragma unroll
     for (int kyi = 0; kyi < NKY; ++kyi) {
-      const int iy = 2 * oy + (WKY ? wave : kyi) - p.P;
+      const int iy = S * oy + (WKY ? wave : kyi) - p.P;
       int off = (okb && (unsigned)iy < (unsigned)p.H) ? xbase + iy * p.iH * 4 : OOB;
       asm volatile("" : "+v"(off));
 #pragma unroll
@@ -152,8 +156,8 @@ __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int fl = J * n + j, kx = fl / CI, ci = fl & (CI - 1);
-        const int tap = (kz * 4 + wave) * 4 + kx, co = 16 * mt + 4 * q;
-        if (co < CO) *reinterpret_cast<f32x4 *>(slab0 + (size_t)(tap * CI + ci) * CO + co) = acc[0][j][mt];
+        const int tap = (kz * KS + wave) * KS + kx, co = 16 * mt + 4 * q;
+        if (co < CO && kx < KS) *reinterpret_cast<f32x4 *>(slab0 + (size_t)(tap * CI + ci) * CO + co) = acc[0][j][mt];
       }
     return;
   }
@@ -179,8 +183,8 @@ __global__ __launch_bounds__(256) void bww_s2_k(Dev p) {
     }
     // D row = output channel 16 mt + 4 q + r (r = register), column = float J n + j of the run: x-tap, input channel
     const int fl = J * n + j, kx = fl / CI, ci = fl & (CI - 1);
-    const int tap = (kz * 4 + ky) * 4 + kx, co = 16 * mt + 4 * q;
-    if (co < CO) *reinterpret_cast<f32x4 *>(slab + (size_t)(tap * CI + ci) * CO + co) = s;
+    const int tap = (kz * KS + ky) * KS + kx, co = 16 * mt + 4 * q;
+    if (co < CO && kx < KS) *reinterpret_cast<f32x4 *>(slab + (size_t)(tap * CI + ci) * CO + co) = s;
   }
 }
 
@@ -194,9 +198,9 @@ static int64_t span_of(const tem_view &v) {
 static thread_local char *g_name = nullptr;
 static thread_local int g_name_len = 0;
 
-template <int CI, int CO>
+template <int CI, int CO, int KS = 4, int S = 2>
 static int run(Dev p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
-  constexpr int MT = (CO + 15) / 16, J = CI / 4, NACC = 4 * J * MT;
+  constexpr int MT = (CO + 15) / 16, J = CI / 4, NACC = KS * J * MT;
   const size_t lds_bytes = CI == 32 ? 0 : (size_t)4 * NACC * 64 * 16;
   // row ranges: 128 (two workgroups per CU with the four kz) where the LDS sum leaves room for two, else 64; at least ~4
   // rows per wave
@@ -209,15 +213,15 @@ static int run(Dev p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   if (R < 1) return TEM_EUNSUPPORTED;
   p.R = R;
   if (nslab_out) *nslab_out = R;
-  if (g_name) snprintf(g_name, g_name_len, "bww_s2_k<%d, %d>", CI, CO);
+  if (g_name) snprintf(g_name, g_name_len, "bww_s2_k<%d, %d, %d, %d>", CI, CO, KS, S);
   if (dry) return TEM_OK;
   static bool attr = false;
   if (!attr && lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)bww_s2_k<CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void *)bww_s2_k<CI, CO, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL((bww_s2_k<CI, CO>), dim3((unsigned)R, 4), dim3(256), lds_bytes, st, p);
+  hipLaunchKernelGGL((bww_s2_k<CI, CO, KS, S>), dim3((unsigned)R, KS), dim3(256), lds_bytes, st, p);
   TEM_CHECK_LAUNCH();
   return TEM_OK;
 }
@@ -225,7 +229,9 @@ static int run(Dev p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
 static int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
   const tem_view &i0 = a->in0, &g = a->dout;
   if (a->in1.ptr) return TEM_EUNSUPPORTED;
-  if (a->kd != 4 || a->kh != 4 || a->kw != 4 || a->sd != 2 || a->sh != 2 || a->sw != 2) return TEM_EUNSUPPORTED;
+  const bool k4s2 = a->kd == 4 && a->kh == 4 && a->kw == 4 && a->sd == 2 && a->sh == 2 && a->sw == 2;
+  const bool k3s1 = a->kd == 3 && a->kh == 3 && a->kw == 3 && a->sd == 1 && a->sh == 1 && a->sw == 1;
+  if (!k4s2 && !k3s1) return TEM_EUNSUPPORTED;
   if (a->pd != a->ph || a->ph != a->pw) return TEM_EUNSUPPORTED;
   static int enabled = -1;
   if (enabled < 0) { const char *v = getenv("TEM_BWW_S2"); enabled = v ? atoi(v) : 1; }
@@ -237,7 +243,7 @@ static int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_
   const int64_t rows = (int64_t)g.N * g.D * g.H;
   if (rows > (1 << 22) || g.H > 4096 || g.D > 4096) return TEM_EUNSUPPORTED;                 // range of the magic divisions
   const int CI = i0.C, CO = g.C;
-  const int64_t stride = a->slab_stride ? a->slab_stride : (int64_t)64 * CI * CO;
+  const int64_t stride = a->slab_stride ? a->slab_stride : (int64_t)(k4s2 ? 64 : 27) * CI * CO;
   if (!dry && (((uintptr_t)a->slabs & 15) || stride % 4)) return TEM_EUNSUPPORTED;           // 16-byte slab stores
   Dev p{};
   p.in = i0.ptr; p.iN = (int)i0.sN; p.iD = (int)i0.sD; p.iH = (int)i0.sH; p.iW = (int)i0.sW;
@@ -249,6 +255,15 @@ static int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_
   p.magicOH = magic_for(g.H); p.magicOD = magic_for(g.D);
   p.slabs = a->slabs; p.slab_stride = stride;
   // (8 -> 8, g.d1b / d.d1b: half of every m-tile would be zeros -- 73 vs 51 us measured; left to bww_lds_k's x-shift form)
+  if (k3s1) {
+    // the 3x3x3 layers the Winograd-domain kernel leaves alone (hip_ops.WINO_MIN_VOXELS): g.u2a, d.d3a
+    static int k3 = -1;
+    if (k3 < 0) { const char *v = getenv("TEM_BWW_S2_K3"); k3 = v ? atoi(v) : 1; }
+    if (!k3 || (int64_t)g.D * g.H * g.W > 40000) return TEM_EUNSUPPORTED;
+    if (CI == 16 && CO == 32) return run<16, 32, 3, 1>(p, a->nslab, st, dry, nslab_out);
+    if (CI == 32 && CO == 32) return run<32, 32, 3, 1>(p, a->nslab, st, dry, nslab_out);
+    return TEM_EUNSUPPORTED;
+  }
   if (CI == 8 && CO == 16) return run<8, 16>(p, a->nslab, st, dry, nslab_out);     // g.u1b (transposed conv: input and gradient swapped)
   if (CI == 16 && CO == 16) return run<16, 16>(p, a->nslab, st, dry, nslab_out);   // g.d2b
   if (CI == 16 && CO == 32) return run<16, 32>(p, a->nslab, st, dry, nslab_out);   // g.u2b
