@@ -16,6 +16,9 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; must be set before HIP initialises
+# The step runs on three streams and RCCL adds its own: with HIP's default of 4 hardware queues per process two of them
+# share a queue and serialize (measured: 9.49 instead of 8.51 ms/step with the exchange on).  Read when HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -100,7 +103,23 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
     ndev = max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank % ndev)           # (rehearsals put several ranks on one card)
-    dist = world > 1
+    # TEM_DP_FORCE_EXCHANGE=1 under torch.distributed.run with one rank: a process group of one that still issues
+    # the gradient exchange -- the one-GPU rehearsal of the RCCL path (init, broadcast, bucketed all-reduce, barrier)
+    dist = world > 1 or ("RANK" in os.environ and os.environ.get("TEM_DP_FORCE_EXCHANGE", "0") == "1")
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner through C stdio when its
+    # communicator comes up, so file descriptor 1 points at stderr until the line is due
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush(); libc.fflush(None)
+        os.dup2(real_stdout, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)
+
     if dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -152,6 +171,8 @@ def main():
     if args.no_kernel_profile:
         if rank == 0:
             print(f"ms_per_step {dt / args.steps * 1e3:.3f} (timed steps only, no JSON)", file=sys.stderr)
+        if dist:
+            torch.distributed.destroy_process_group()
         return
     if rank == 0:
         st = model._steps[B]
@@ -268,7 +289,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "losses": [float(v) for v in losses],
         }
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -86,3 +86,24 @@ def test_two_rank_step_matches_oracle(tmp_path, rank_launcher, oracle_lib, is3d)
         big = np.abs(ref) >= 1e-2 * np.abs(ref).max()
         assert np.abs(th - want)[big].max() < 0.15 * 2e-4 and np.abs(th - want).max() <= 2 * 2.05 * 2e-4, key
         o += nk
+
+
+def test_one_rank_rccl_exchange_is_identity(tmp_path, rank_launcher):
+    """RCCL itself (backend "nccl") on the one card of the box: a process group of ONE rank that still issues the
+    parameter broadcast and both gradient buckets' all-reduce on the step's streams (TEM_DP_FORCE_EXCHANGE=1).  A sum
+    over one replica is the identity and grad_scale is 1, so parameters, moments and losses must equal, bit for bit,
+    those of the same two steps without any exchange."""
+    outs = []
+    for tag, env in (("rccl", {"TEM_DIST_BACKEND": "nccl", "TEM_DP_FORCE_EXCHANGE": "1"}),
+                     ("plain", {"TEM_DIST_BACKEND": "gloo"})):
+        d = tmp_path / tag
+        d.mkdir()
+        res = rank_launcher([sys.executable, os.path.join(ROOT, "tests", "tools", "dp_rank.py"), str(d), "3d"],
+                            ranks=1, env=env, timeout=600)
+        assert res["rc"] == [0], "\n".join(res["tail"])
+        outs.append(np.load(os.path.join(d, "rank0.npz")))
+    a, b = outs
+    assert int(a["step"][0]) == 2
+    for k in a.files:
+        if k != "ckpt":
+            assert np.array_equal(a[k], b[k]), k

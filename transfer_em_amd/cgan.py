@@ -248,6 +248,15 @@ class EM2EM(object):
         self.pg = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if self._dist() else 1
         self.rank = torch.distributed.get_rank(process_group) if self._dist() else 0
+        # the exchange step runs when there is more than one replica; TEM_DP_FORCE_EXCHANGE=1 makes a one-rank
+        # process group issue it too (sum over one rank = identity): a one-GPU rehearsal of the RCCL path
+        self.exchange = self.world_size > 1 or (self._dist() and os.environ.get("TEM_DP_FORCE_EXCHANGE", "0") == "1")
+        from . import HW_QUEUES_SET_LATE
+        if self.exchange and two_streams and (HW_QUEUES_SET_LATE or int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 5):
+            import warnings
+            warnings.warn("data-parallel EM2EM: the step's three streams and RCCL's share HIP's hardware queues "
+                          "(GPU_MAX_HW_QUEUES, default 4) and partly serialize (~10 % of a step); export "
+                          "GPU_MAX_HW_QUEUES=8 or import transfer_em_amd before the first GPU call")
         self.seed = D.replica_seed(seed, self.rank)  # independent dropout stream per replica
 
         sd = weight_seeds
@@ -365,10 +374,10 @@ class EM2EM(object):
         """Sum one gradient bucket over the replicas on `stream` (RCCL over xGMI; the Adam kernel scales by 1/world).
         The collective is enqueued behind the work already on `stream` and the bucket's Adam launches behind it;
         the other streams keep computing meanwhile."""
-        if self.world_size == 1:
+        if not self.exchange:
             return
         with torch.cuda.stream(stream):
-            D.allreduce_sum_(self.grad_buckets[key], self.pg)
+            D.allreduce_sum_(self.grad_buckets[key], self.pg, force=True)
 
     def _run_streams(self, st, trace=None, hop=False, lists=None):
         """Enqueue the step's launch lists on their streams.  `trace` (bench.py): list receiving
@@ -456,7 +465,7 @@ class EM2EM(object):
         the gradient computation and the optimizer update are two graphs with the all-reduce between them."""
         torch.cuda.synchronize(self.device)
         pool = torch.cuda.graph_pool_handle()
-        if self.world_size == 1 and self.two_streams:
+        if not self.exchange and self.two_streams:
             g_step = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_step, pool=pool):
                 self._step_fused(st)
@@ -477,16 +486,16 @@ class EM2EM(object):
             if st.graphs is not None:
                 st.graphs[0].replay()
                 if len(st.graphs) == 2:
-                    if self.world_size > 1:
-                        D.allreduce_sum_(self.grad_all, self.pg)
+                    if self.exchange:
+                        D.allreduce_sum_(self.grad_all, self.pg, force=True)
                     st.graphs[1].replay()
                 return st.losses[:7].to(torch.float32)
         if self.two_streams:
             self._step_fused(st)
         else:
             self._compute(st)
-            if self.world_size > 1:
-                D.allreduce_sum_(self.grad_all, self.pg)     # RCCL over xGMI (sum; the Adam kernel scales by 1/world)
+            if self.exchange:
+                D.allreduce_sum_(self.grad_all, self.pg, force=True)     # RCCL over xGMI (sum; the Adam kernel scales by 1/world)
             H.run(st.update, H.current_stream())
         st.warm = True
         return st.losses[:7].to(torch.float32)

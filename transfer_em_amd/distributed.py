@@ -15,9 +15,10 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized()
 
 
-def allreduce_sum_(flat, group=None):
-    """In-place sum of `flat` over the process group (no-op without one)."""
-    if is_distributed() and dist.get_world_size(group) > 1:
+def allreduce_sum_(flat, group=None, force=False):
+    """In-place sum of `flat` over the process group (no-op without one, or with one rank unless `force`:
+    the one-GPU rehearsal of the collective, EM2EM.exchange)."""
+    if is_distributed() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
