@@ -158,7 +158,8 @@ class _CompiledStep:
         # main: generator G call sites; third: generator F call sites (their kernels overlap in the
         # ramp-up / ramp-down of each other's grids).  Measured and rejected (MI355X, 132^3): moving the
         # generators' kernel-gradient launches to two more streams (16.4 vs 15.75 ms/step -- the extra
-        # LDS-bound kernels only steal CUs from the dependent chains) and HIP stream priorities for the
+        # LDS-bound kernels only steal CUs from the dependent chains; again in round 2 with GPU_MAX_HW_QUEUES=8, so
+        # that no two streams share a hardware queue: 9.35 vs 8.52 ms/step) and HIP stream priorities for the
         # chains (17.9 ms/step).
         # (also measured and rejected: starting the F chain a few layers behind the G chain so that one chain's
         # full-resolution layers meet the other's 27^3..60^3 layers -- 9.74-9.77 vs 9.73 ms/step)
