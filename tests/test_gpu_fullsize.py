@@ -77,9 +77,9 @@ def _generic_kernel_gradient(H, x, g, k, s, pad):
 
 
 @pytest.mark.parametrize("ci,co,n,pad,k", [(16, 32, 54, 1, 4), (16, 16, 60, 0, 4), (8, 16, 100, 1, 4), (16, 16, 100, 0, 3),
-                                           (32, 32, 54, 0, 3)])
+                                           (32, 32, 54, 0, 3), (8, 8, 130, 0, 4), (8, 8, 94, 0, 4)])
 def test_kernel_gradient_full_size_vs_generic(H, ci, co, n, pad, k):
-    """bww_s2_k (k4 s2, direct fragments) and wino_bww_k (k3 s1, buffer-loaded gradient voxels) vs the global-load kernel
+    """bww_s2_k / bww_s2tb_k (k4 s2, direct fragments; 8 -> 8: two-block rows) and wino_bww_k (k3 s1, buffer-loaded gradient voxels) vs the global-load kernel
     at the step's shapes: float32 sums of 10^5..10^6 terms each, compared at 1e-5 of the largest entry."""
     from transfer_em_amd.models.params import ParamSet
     s = 2 if k == 4 else 1
@@ -88,7 +88,7 @@ def test_kernel_gradient_full_size_vs_generic(H, ci, co, n, pad, k):
     P = ParamSet({"w": (k, k, k, ci, co)}, "cuda", seed=1)
     ws = H.GradWorkspace(P, 1)
     l = H.bww_launch("t", x, g, ws, "w", 0, k, s, pad)
-    assert l.meta["kernel"].startswith("bww_s2_k" if k == 4 else "wino_bww_k"), l.meta["kernel"]
+    assert l.meta["kernel"].startswith(("bww_s2tb_k" if ci == co == 8 else "bww_s2_k") if k == 4 else "wino_bww_k"), l.meta["kernel"]
     H.run([l] + ws.reduce_launches("r"))
     torch.cuda.synchronize()
     got = P.g("w").clone().cpu().numpy().reshape(-1)
