@@ -40,6 +40,7 @@ struct Ep32 {
   const float *gate; int32_t gN, gD, gH, gW; float gate_slope;
   const uint8_t *keep_mask;      // dropout bits drawn by the forward pass (keep_mode 2) or NULL
   int32_t doz, doy, dox, dD, dH, dW;
+  int32_t gbytes, mbytes;        // bytes one sample of the gate view spans / bytes of the keep mask: buffer ranges
 };
 
 struct Dev {
@@ -166,6 +167,23 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   float *const out0n = p.out0 + (size_t)n * p.o0N, *const out1n = EP == 2 ? p.out1 + (size_t)n * p.o1N : nullptr;
   const float *const gaten = EP >= 1 ? ep.gate + (size_t)n * ep.gN : nullptr;
   const bool in0c = EP != 2 || co < p.CO0;                   // this lane's channel goes to out0 (with the full epilogue)
+  // The epilogue runs 16 times per lane and plane on the vector pipe the transforms need: everything that does not depend on
+  // the output voxel is a lane constant or a scalar.  The lane's destination tensor (EP 2: out0 or out1 by its channel) is
+  // chosen once; gate values and keep bytes come through buffer descriptors -- per load ONE select (offset or out-of-range
+  // = zero), the 2x2 voxel's displacement in the scalar offset; the keep bit of a lane is always bit co & 7 of its byte.
+  float *const obase = EP == 2 ? (in0c ? out0n : out1n) : out0n;      // (EP 0, 1: wave-uniform -- scalar base + 32-bit offset)
+  const int oco = in0c ? co : co - p.CO0;
+  const int oD = in0c ? p.o0D : p.o1D, oH = in0c ? p.o0H : p.o1H, oW = in0c ? p.o0W : p.o1W;
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)gaten, 0, EP >= 1 ? ep.gbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void *)ep.keep_mask, 0, EP == 2 ? ep.mbytes : 0, 0x00020000);
+  const int mpv = EP == 2 ? p.CO0 >> 3 : 0;                  // mask bytes per voxel
+  const uint32_t kbit = 1u << (co & 7);
+  int gso[4], mso[4];                                        // scalar offsets of the 2x2 voxels (bytes)
+#pragma unroll
+  for (int o4 = 0; o4 < 4; ++o4) {
+    gso[o4] = EP >= 1 ? ((o4 >> 1) * ep.gH + (o4 & 1) * ep.gW) * 4 : 0;
+    mso[o4] = EP == 2 ? ((o4 >> 1) * ep.dW + (o4 & 1)) * mpv : 0;
+  }
 
   // A role: this lane's (tile, channel pair) of the wave's row block
   const int tA = min(grp * 16 + m, ntile - 1);
@@ -199,30 +217,32 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     for (int o4 = 0; o4 < 4; ++o4) tok4 |= ((tok && oy + (o4 >> 1) < p.OH && ox + (o4 & 1) < p.OW) ? 1u : 0u) << (4 * r + o4);
     tyx[r] = ((uint32_t)oy << 16) | (uint32_t)ox;
   }
-  auto tile_geom = [&](int r, int oz, int &o0, int &o1, int &go, uint32_t &e0, uint32_t &okm) {
+  auto tile_geom = [&](int r, int oz, int &o0, int &go, int &mb, uint32_t &okm) {
     uint32_t yx = tyx[r];
     asm volatile("" : "+v"(yx));                             // per-use recompute: no per-output offsets hoisted out of the step loop
     const int oy = (int)(yx >> 16), ox = (int)(yx & 0xffffu);
     okm = oz < p.OD ? (tok4 >> (4 * r)) & 15u : 0u;
-    o0 = oz * p.o0D + oy * p.o0H + ox * p.o0W + co;
-    o1 = EP == 2 ? oz * p.o1D + oy * p.o1H + ox * p.o1W + (co - p.CO0) : 0;
-    go = EP >= 1 ? oz * ep.gD + oy * ep.gH + ox * ep.gW + co : 0;
-    e0 = EP == 2 ? ((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint32_t)p.CO0 + co : 0u;
+    o0 = oz * oD + oy * oH + ox * oW + oco;
+    go = EP >= 1 ? (oz * ep.gD + oy * ep.gH + ox * ep.gW + co) * 4 : 0;
+    mb = EP == 2 ? (int)(((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint32_t)mpv) + (co >> 3) : 0;
   };
   auto fetch_ep = [&](int oz) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int o0, o1, go;
-      uint32_t e0, okm;
-      tile_geom(r, oz, o0, o1, go, e0, okm);
+      int o0, go, mb;
+      uint32_t okm;
+      tile_geom(r, oz, o0, go, mb, okm);
       if (!in0c) okm = 0;
 #pragma unroll
       for (int o4 = 0; o4 < 4; ++o4) {
         const bool okf = (okm >> o4) & 1u;
-        gv[r * 4 + o4] = gaten[okf ? go + (o4 >> 1) * ep.gH + (o4 & 1) * ep.gW : 0];
+        int goff = okf ? go : (int)0x80000000;
+        asm volatile("" : "+v"(goff));
+        gv[r * 4 + o4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grs, goff, gso[o4], 0));
         if (EP == 2) {
-          const uint32_t e = e0 + ((o4 >> 1) * ep.dW + (o4 & 1)) * (uint32_t)p.CO0;
-          kb[r * 4 + o4] = ep.keep_mask[okf ? (e >> 3) : 0];
+          int moff = okf ? mb : (int)0x80000000;
+          asm volatile("" : "+v"(moff));
+          kb[r * 4 + o4] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(mrs, moff, mso[o4], 0);
         }
       }
     }
@@ -237,9 +257,9 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     for (int b = 0; b < 2; ++b) at4(yx[0][b], yx[1][b], yx[2][b], yx[3][b], yy[0][b], yy[1][b]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int o0, o1, go;
-      uint32_t e0, okm;
-      tile_geom(r, oz, o0, o1, go, e0, okm);
+      int o0, go, mb;
+      uint32_t okm;
+      tile_geom(r, oz, o0, go, mb, okm);
 #pragma unroll
       for (int o4 = 0; o4 < 4; ++o4) {
         const bool ok = (okm >> o4) & 1u;
@@ -247,14 +267,10 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
         if (EP == 0) val = val > 0.f ? val : ep.slope * val;
         if (EP >= 1 && in0c) {
           val = gv[r * 4 + o4] > 0.f ? val : ep.gate_slope * val;
-          if (EP == 2) {
-            const uint32_t e = e0 + ((o4 >> 1) * ep.dW + (o4 & 1)) * (uint32_t)p.CO0;
-            val = ((kb[r * 4 + o4] >> (e & 7u)) & 1u) ? 2.f * val : 0.f;
-          }
+          if (EP == 2) val = (kb[r * 4 + o4] & kbit) ? 2.f * val : 0.f;
         }
         if (!(p.dbg & 1)) {
-          if (ok && in0c) out0n[o0 + (o4 >> 1) * p.o0H + (o4 & 1) * p.o0W] = val;
-          if (EP == 2 && ok && !in0c) out1n[o1 + (o4 >> 1) * p.o1H + (o4 & 1) * p.o1W] = val;
+          if (ok) obase[o0 + (o4 >> 1) * oH + (o4 & 1) * oW] = val;
         }
       }
     }
@@ -529,6 +545,9 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
     if (g.N != o0.N || g.D != o0.D || g.H != o0.H || g.W != o0.W || g.C < o0.C) return TEM_ESHAPE;
     if (!fits32(g) || e.slope != 1.f) return TEM_EUNSUPPORTED;
     q.gate = g.ptr; q.gN = (int)g.sN; q.gD = (int)g.sD; q.gH = (int)g.sH; q.gW = (int)g.sW;
+    const int64_t gspan = (int64_t)(g.D - 1) * g.sD + (int64_t)(g.H - 1) * g.sH + (int64_t)(g.W - 1) * g.sW + g.C;
+    if (gspan >= ((int64_t)1 << 29)) return TEM_EUNSUPPORTED;            // byte offsets below 2^31
+    q.gbytes = (int)(gspan * 4);
     EP = 1;
   }
   if (e.dropout || a->out1.ptr) {
@@ -540,6 +559,8 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
     q.dD = e.drop_dims[0] ? e.drop_dims[0] : o0.D; q.dH = e.drop_dims[0] ? e.drop_dims[1] : o0.H;
     q.dW = e.drop_dims[0] ? e.drop_dims[2] : o0.W;
     if ((int64_t)o0.N * q.dD * q.dH * q.dW * o0.C >= ((int64_t)1 << 32)) return TEM_EUNSUPPORTED;
+    if (o0.C % 8) return TEM_EUNSUPPORTED;                               // a lane's keep bit = bit (co & 7) of byte voxel * C/8 + co/8
+    q.mbytes = (int)(((int64_t)o0.N * q.dD * q.dH * q.dW * o0.C + 7) / 8);
     EP = 2;
   }
 #define WINO_CASE(ci, co, ni, epi) if (CI == ci && CO == co && EP == epi) return run_best<ci, co, ni, epi>(p, st, dry);
