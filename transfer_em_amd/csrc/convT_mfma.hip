@@ -54,7 +54,11 @@ struct Dev {
 
 // NCLS: (r_z, r_y) classes handled per workgroup on ONE loaded patch (their B fragments all stay in registers:
 // NCLS * 2 C_in VGPRs) -- 4 for C_in 8, 2 (both r_y of one r_z) for C_in 16, 1 for C_in 32
-template <int CI, int CO, int PF, int NCLS>
+// EPM: compiled epilogue -- 0: everything by run-time flags; 1: Conv3DTranspose forward of the train step (no gate, no
+// skip-gradient; Dropout by the keep bits drawn ahead of the launch; LeakyReLU); 2: input-gradient (gate, optional
+// skip-gradient add, no Dropout).  The epilogue runs once per 4 output floats of a lane on the vector pipe, which at
+// C_in = 8 has fewer MFMA cycles to hide under than it takes: what a launch does not use is not compiled into it.
+template <int CI, int CO, int PF, int NCLS, int EPM>
 __global__ __launch_bounds__(256) void convT_mfma_k(Dev p, const float *__restrict__ wgt) {
   constexpr int CIP = CI + 2;
   constexpr int NT = 2 * CO / 16;                 // n-tiles over the columns (r_x, co)
@@ -171,21 +175,27 @@ __global__ __launch_bounds__(256) void convT_mfma_k(Dev p, const float *__restri
     const int qy = p.nQx == 1 ? v : (int)__umulhi((uint32_t)v, p.magicQx), qx = v - qy * p.nQx;
     q.oy = 2 * (Qy0 + qy) + ry - p.P; q.ox = 2 * (p.Qlo_x + qx) + erx - p.P;
     q.valid = v < L && (unsigned)q.oy < (unsigned)p.OH && (unsigned)q.ox < (unsigned)p.OW;
-    int goff = q.valid ? (n * ep.gN + oz * ep.gD + q.oy * ep.gH + q.ox * ep.gW + eco) * 4 : (int)0x80000000;
-    asm volatile("" : "+v"(goff));
-    const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(grs, goff, 0, 0);
-    q.g4 = make_float4(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z), __uint_as_float(g.w));
-    const int az = oz - ep.aoz, ay = q.oy - ep.aoy, ax = q.ox - ep.aox;
-    const bool ain = q.valid && (unsigned)az < (unsigned)ep.aDd && (unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw;
-    int aoff = ain ? (n * ep.aN + az * ep.aD + ay * ep.aH + ax * ep.aW + eco) * 4 : (int)0x80000000;
-    asm volatile("" : "+v"(aoff));
-    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff, 0, 0);
-    q.a4 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
-    // keep bits drawn ahead of this launch (keep_mode 2): the byte of the lane's channel quad
-    const uint32_t e3 = (uint32_t)((((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (q.oy + ep.doy)) * ep.dW + (q.ox + ep.dox)) * (uint64_t)CO + eco) >> 3);
-    int moff = q.valid ? (int)e3 : (int)0x80000000;
-    asm volatile("" : "+v"(moff));
-    q.kb = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(mrs, moff, 0, 0);
+    q.g4 = make_float4(0.f, 0.f, 0.f, 0.f); q.a4 = q.g4; q.kb = 0;
+    if (EPM != 1) {
+      int goff = q.valid ? (n * ep.gN + oz * ep.gD + q.oy * ep.gH + q.ox * ep.gW + eco) * 4 : (int)0x80000000;
+      asm volatile("" : "+v"(goff));
+      const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(grs, goff, 0, 0);
+      q.g4 = make_float4(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z), __uint_as_float(g.w));
+      const int az = oz - ep.aoz, ay = q.oy - ep.aoy, ax = q.ox - ep.aox;
+      const bool ain = q.valid && (unsigned)az < (unsigned)ep.aDd && (unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw;
+      int aoff = ain ? (n * ep.aN + az * ep.aD + ay * ep.aH + ax * ep.aW + eco) * 4 : (int)0x80000000;
+      asm volatile("" : "+v"(aoff));
+      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff, 0, 0);
+      q.a4 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    }
+    if (EPM != 2) {
+      // keep bits drawn ahead of this launch (keep_mode 2): the byte of the lane's channel quad = voxel * C_out/8 + eco/8
+      // (C_out is a multiple of 8 whenever there is a mask; the element count is below 2^32: host)
+      const uint32_t vox = (((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (q.oy + ep.doy)) * ep.dW + (q.ox + ep.dox);
+      int moff = q.valid ? (int)(vox * (uint32_t)(CO >> 3) + (uint32_t)(eco >> 3)) : (int)0x80000000;
+      asm volatile("" : "+v"(moff));
+      q.kb = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(mrs, moff, 0, 0);
+    }
     return q;
   };
   auto finish = [&](const f32x4 &acc, const Prep &q, int oz) {
@@ -196,18 +206,18 @@ __global__ __launch_bounds__(256) void convT_mfma_k(Dev p, const float *__restri
     const int oy = q.oy, ox = q.ox;
     const bool valid = q.valid;
     float vv[4] = {v4.x + q.a4.x, v4.y + q.a4.y, v4.z + q.a4.z, v4.w + q.a4.w};
-    if (ep.gate) {
+    if (EPM == 2 || (EPM == 0 && ep.gate)) {
       vv[0] = q.g4.x > 0.f ? vv[0] : ep.gate_slope * vv[0];
       vv[1] = q.g4.y > 0.f ? vv[1] : ep.gate_slope * vv[1];
       vv[2] = q.g4.z > 0.f ? vv[2] : ep.gate_slope * vv[2];
       vv[3] = q.g4.w > 0.f ? vv[3] : ep.gate_slope * vv[3];
     }
-    if (ep.dropout) {                                          // kernel-uniform
-      const uint64_t e = ((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint64_t)CO + eco;
+    if (EPM == 1 || (EPM == 0 && ep.dropout)) {                // kernel-uniform
       uint32_t bits;
-      if (ep.keep_mode == 2) {
-        bits = (q.kb >> (uint32_t)(e & 4u)) & 15u;              // (fetched by prep; zero for lanes without a voxel)
+      if (EPM == 1 || ep.keep_mode == 2) {
+        bits = (q.kb >> (uint32_t)(eco & 4)) & 15u;             // (fetched by prep; zero for lanes without a voxel)
       } else {
+        const uint64_t e = ((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint64_t)CO + eco;
         const Philox128 ph = ds.block(e >> 7);
         const uint32_t eb = (uint32_t)(e & 127);
         bits = 0;
@@ -282,7 +292,7 @@ static thread_local int g_name_len = 0;
 static int floordiv2(int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }
 
 template <int CI, int CO, int PF, int NCLS>
-int run(Dev p, int N, const float *w, hipStream_t st, bool dry) {
+int run(Dev p, int N, const float *w, hipStream_t st, bool dry, int epm) {
   constexpr int CIP = CI + 2, CPV = CI / 4;
   // o + P = 2Q + r  =>  Q in [floor(P/2), floor((O-1+P)/2)]
   p.Qlo_x = floordiv2(p.P); p.nQx = floordiv2(p.OW - 1 + p.P) - p.Qlo_x + 1;
@@ -304,7 +314,7 @@ int run(Dev p, int N, const float *w, hipStream_t st, bool dry) {
   p.magicQx = magic_for(p.nQx);
   p.magicCols = magic_for(p.cols);
   if (dry) {
-    if (g_name) snprintf(g_name, g_name_len, "convT_mfma_k<%d, %d, %d, %d>", CI, CO, PF, NCLS);
+    if (g_name) snprintf(g_name, g_name_len, "convT_mfma_k<%d, %d, %d, %d, %d>", CI, CO, PF, NCLS, epm);
     return TEM_OK;
   }
   static int dbg = -1;
@@ -314,7 +324,9 @@ int run(Dev p, int N, const float *w, hipStream_t st, bool dry) {
   if (dbg & 8)
     fprintf(stderr, "convT_mfma<%d,%d> O=%dx%dx%d P=%d: nQ=%dx%dx%d TY=%d bands=%d blocks=%d lds=%zu\n", CI, CO, p.OD, p.OH,
             p.OW, p.P, p.nQz, p.nQy, p.nQx, p.TY, p.nband, nblocks, lds_bytes);
-  hipLaunchKernelGGL((convT_mfma_k<CI, CO, PF, NCLS>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
+  if (epm == 1) hipLaunchKernelGGL((convT_mfma_k<CI, CO, PF, NCLS, 1>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
+  else if (epm == 2) hipLaunchKernelGGL((convT_mfma_k<CI, CO, PF, NCLS, 2>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
+  else hipLaunchKernelGGL((convT_mfma_k<CI, CO, PF, NCLS, 0>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
   TEM_CHECK_LAUNCH();
   return TEM_OK;
 }
@@ -369,7 +381,7 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   q.dW = e.drop_dims[0] ? e.drop_dims[2] : o0.W;
   {
     const int64_t melems = (int64_t)o0.N * q.dD * q.dH * q.dW * o0.C;
-    if (melems >= ((int64_t)1 << 33)) return TEM_EUNSUPPORTED;
+    if (melems >= ((int64_t)1 << 32)) return TEM_EUNSUPPORTED;
     q.mbytes = (int)((melems + 7) / 8);
     auto span = [](const tem_view &v) {
       return (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH + (int64_t)(v.W - 1) * v.sW + v.C;
@@ -378,7 +390,14 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
       return TEM_EUNSUPPORTED;                     // byte offsets of the epilogue's buffer loads stay below 2^31
   }
   const int CI = i0.C, CO = o0.C, N = i0.N;
-#define CT_CASE(ci, co, pf, ncls) if (CI == ci && CO == co) return run<ci, co, pf, ncls>(p, N, a->w, st, dry);
+  static int epm_on = -1;
+  if (epm_on < 0) { const char *v = getenv("TEM_CONVT_EPM"); epm_on = v ? atoi(v) : 1; }
+  int epm = 0;
+  if (epm_on) {
+    if (q.dropout && q.keep_mode == 2 && !q.gate && !q.add) epm = 1;
+    else if (!q.dropout && q.gate) epm = 2;
+  }
+#define CT_CASE(ci, co, pf, ncls) if (CI == ci && CO == co) return run<ci, co, pf, ncls>(p, N, a->w, st, dry, epm);
   CT_CASE(16, 8, 12, 1)     // g.u1b forward (Conv3DTranspose 16 -> 8)
   CT_CASE(32, 16, 12, 1)    // g.u2b forward
   CT_CASE(8, 8, 12, 1)      // input-gradient of g.d1b / d.d1b    (more classes per patch measured no faster)
