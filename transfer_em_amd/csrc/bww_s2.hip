@@ -400,7 +400,8 @@ static int run(Dev p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   const size_t lds_bytes = CI == 32 ? 0 : (size_t)4 * NACC * 64 * 16;
   // row ranges: 128 (two workgroups per CU with the four kz) where the LDS sum leaves room for two, else 64; at least ~4
   // rows per wave
-  int R = lds_bytes <= 80 * 1024 ? 128 : 64;
+  // (32 input channels: a slab is 110-260 KB; 64 ranges x kz = one workgroup per CU already, and half the slab traffic of 128)
+  int R = (lds_bytes <= 80 * 1024 && CI != 32) ? 128 : 64;
   static int rr = -1;
   if (rr < 0) { const char *v = getenv("TEM_BWW_S2_R"); rr = v ? atoi(v) : 0; }
   if (rr > 0) R = rr;
