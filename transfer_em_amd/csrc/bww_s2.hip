@@ -436,7 +436,7 @@ static int run_tb(Dev p, int max_slabs, hipStream_t st, bool dry, int *nslab_out
   if (R < 1) return TEM_EUNSUPPORTED;
   p.R = R;
   if (nslab_out) *nslab_out = R;
-  if (g_name) snprintf(g_name, g_name_len, "bww_s2tb_k");
+  if (g_name) snprintf(g_name, g_name_len, "bww_s2tb_k<%d>", nb == 6 ? 6 : 8);
   if (dry) return TEM_OK;
   static bool attr = false;
   if (!attr) {
