@@ -150,11 +150,28 @@ class _CompiledStep:
         #         the adversarial term (joined into the generator sweep) -> discriminator sweep -> reduction
         L_ = lambda *plans: [l for pl in plans for l in pl.launches]
         main, side, third = [], [], []
-        # side: discriminators (one stream for both: a stream per discriminator measured no different)
-        side += [("wait", "inputs"), flips["dx"], flips["dy"], ("wait", "cast")] + L_(d_xr, d_yr)
-        side += [("wait", "fake_y")] + L_(d_yf) + [("wait", "fake_x")] + L_(d_xf)
-        side += [loss[0], loss[1]] + loss[6:10] + L_(a_dy, a_dx) + [("record", "adv")]
-        side += L_(w_dxr, w_dxf, w_dyr, w_dyf) + red["dx"] + red["dy"] + [("record", "side_done")]
+        # side: discriminators
+        # One stream per discriminator (8.17 -> 8.12 ms/step: the generator sweeps wait ~90 us for the adversarial input-
+        # gradients, which two parallel chains deliver sooner) -- when the process has the hardware queues for five streams
+        # (GPU_MAX_HW_QUEUES >= 6: with HIP's default of 4 two streams would share a queue and serialize; round 1 measured
+        # "no different" under exactly that limit).  TEM_SIDE_SPLIT=0/1 overrides.
+        from . import HW_QUEUES_SET_LATE
+        side_split = int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 6 and not HW_QUEUES_SET_LATE and not m.use_graph
+        #   (graph replay: 13.2 instead of 8.2 ms/step with the fourth branch -- the graph executor runs fewer branches in parallel)
+        if os.environ.get("TEM_SIDE_SPLIT") in ("0", "1"):
+            side_split = os.environ["TEM_SIDE_SPLIT"] == "1"
+        side2 = []
+        if side_split:
+            side += [("wait", "inputs"), flips["dx"], ("wait", "cast")] + L_(d_xr) + [("wait", "fake_x")] + L_(d_xf)
+            side += [loss[1], loss[6], loss[7]] + L_(a_dx) + [("record", "adv_x")] + L_(w_dxr, w_dxf) + red["dx"]
+            side2 += [("wait", "inputs"), flips["dy"], ("wait", "cast")] + L_(d_yr) + [("wait", "fake_y")] + L_(d_yf)
+            side2 += [loss[0], loss[8], loss[9]] + L_(a_dy) + [("record", "adv_y")] + L_(w_dyr, w_dyf) + red["dy"] + [("record", "side2_done")]
+            side += [("wait", "side2_done"), ("record", "side_done")]
+        else:
+            side += [("wait", "inputs"), flips["dx"], flips["dy"], ("wait", "cast")] + L_(d_xr, d_yr)
+            side += [("wait", "fake_y")] + L_(d_yf) + [("wait", "fake_x")] + L_(d_xf)
+            side += [loss[0], loss[1]] + loss[6:10] + L_(a_dy, a_dx) + [("record", "adv")]
+            side += L_(w_dxr, w_dxf, w_dyr, w_dyf) + red["dx"] + red["dy"] + [("record", "side_done")]
         # main: generator G call sites; third: generator F call sites (their kernels overlap in the
         # ramp-up / ramp-down of each other's grids).  Measured and rejected (MI355X, 132^3): moving the
         # generators' kernel-gradient launches to two more streams (16.4 vs 15.75 ms/step -- the extra
@@ -167,10 +184,10 @@ class _CompiledStep:
         third += [("wait", "inputs"), flips["f"], ("wait", "cast")] + L_(f_f1) + [("record", "fake_x")] + L_(f_f3) + [("wait", "fake_y")] + L_(f_f2)
         main += [loss[3], loss[4]] + L_(b_g3, b_g2) + [("record", "d_fake_x")]
         third += [loss[2], loss[5]] + L_(b_f3, b_f2) + [("record", "d_fake_y")]
-        main += [("wait", "adv"), ("wait", "d_fake_y"), add_y] + L_(b_g1) + red["g"]
-        third += [("wait", "adv"), ("wait", "d_fake_x"), add_x] + L_(b_f1) + red["f"] + [("record", "third_done")]
+        main += [("wait", "adv_y" if side_split else "adv"), ("wait", "d_fake_y"), add_y] + L_(b_g1) + red["g"]
+        third += [("wait", "adv_x" if side_split else "adv"), ("wait", "d_fake_x"), add_x] + L_(b_f1) + red["f"] + [("record", "third_done")]
         main += [("wait", "side_done"), ("wait", "third_done")]
-        self.lists = (main, side, third)
+        self.lists = (main, side, third) + ((side2,) if side_split else ())
 
         # ---- optimizer (cgan.py:218-228); gradients are averaged over ranks by grad_scale
         ws = m.world_size
@@ -191,7 +208,7 @@ class _CompiledStep:
         side_f = cut(side, "side_done") + [("allreduce", "d"), adam["dx"], adam["dy"], ("record", "side_done")]
         third_f = list(third)
         main_f = main[:-2] + [("wait", "third_done"), ("allreduce", "g"), adam["g"], adam["f"], ("wait", "side_done"), tick]
-        self.lists_fused = (main_f, side_f, third_f)
+        self.lists_fused = (main_f, side_f, third_f) + tuple(self.lists[3:])
         self.extra_streams = tuple(torch.cuda.Stream(device=dev) for _ in range(len(self.lists) - 1))
         names = {"inputs", "joined"} | {it[1] for l in self.lists for it in l if isinstance(it, tuple) and it[0] != "allreduce"}
         self.events = {k: torch.cuda.Event() for k in names}
