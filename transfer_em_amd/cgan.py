@@ -206,8 +206,12 @@ class _CompiledStep:
         # key) is a no-op for world_size 1, so single-GPU runs execute the identical kernel sequence.
         cut = lambda lst, name: lst[:next(i for i, it in enumerate(lst) if it == ("record", name))]
         side_f = cut(side, "side_done") + [("allreduce", "d"), adam["dx"], adam["dy"], ("record", "side_done")]
-        third_f = list(third)
-        main_f = main[:-2] + [("wait", "third_done"), ("allreduce", "g"), adam["g"], adam["f"], ("wait", "side_done"), tick]
+        if m.exchange:
+            third_f = list(third)
+            main_f = main[:-2] + [("wait", "third_done"), ("allreduce", "g"), adam["g"], adam["f"], ("wait", "side_done"), tick]
+        else:   # one replica: each generator's update follows its own slab reduction on its own stream
+            third_f = third[:-1] + [adam["f"], third[-1]]
+            main_f = main[:-2] + [adam["g"], ("wait", "third_done"), ("wait", "side_done"), tick]
         self.lists_fused = (main_f, side_f, third_f) + tuple(self.lists[3:])
         self.extra_streams = tuple(torch.cuda.Stream(device=dev) for _ in range(len(self.lists) - 1))
         names = {"inputs", "joined"} | {it[1] for l in self.lists for it in l if isinstance(it, tuple) and it[0] != "allreduce"}
