@@ -1,4 +1,4 @@
-"""Timeline of ONE 132^3 train step under the 3-stream schedule: per launch its stream, start and end (HIP events on
+"""Timeline of ONE 132^3 train step under the multi-stream schedule (G chain, D_x, F chain, D_y): per launch its stream, start and end (HIP events on
 the launch's own stream, relative to the step's first launch) and its stand-alone duration (one stream, nothing else
 on the GPU) -- where the chains wait for each other, where a kernel runs slower beside another one.
    python tests/tools/timeline.py > gpurun_out/timeline.txt"""
@@ -49,7 +49,7 @@ for it in range(NT):
         r[1] += a / NT; r[2] += b / NT
     tot += step_ms / NT
 print(f"step (traced: an event pair around every launch) {tot:.3f} ms; stand-alone sum {sum(alone.values()):.3f} ms")
-busy = [0.0, 0.0, 0.0]
+busy = [0.0] * len(st.lists_fused)
 for l, a, b in rows:
     busy[which.get(id(l), 0)] += b - a
 print("per-stream sum of (end - start): " + ", ".join(f"{v:.3f}" for v in busy))
