@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
       for (int o4 = 0; o4 < 4; ++o4) {
         const bool ok = (okm >> o4) & 1u;
         float val = yy[o4 >> 1][o4 & 1][r];
-        if (EP == 0) val = val > 0.f ? val : ep.slope * val;
+        if (EP == 0) val = fmaxf(val, ep.slope * val);           // LeakyReLU for 0 <= slope <= 1 (host): max instead of compare + select
         if (EP >= 1 && in0c) {
           val = gv[r * 4 + o4] > 0.f ? val : ep.gate_slope * val;
           if (EP == 2) val = (kb[r * 4 + o4] & kbit) ? 2.f * val : 0.f;
@@ -553,6 +553,7 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   Ep32 &q = p.ep;
   if (e.bias || e.add.ptr) return TEM_EUNSUPPORTED;        // no k3 s1 layer of the step has them
   q.slope = e.slope; q.gate_slope = e.gate_slope;
+  if (!(e.slope >= 0.f && e.slope <= 1.f)) return TEM_EUNSUPPORTED;      // the epilogue takes max(v, slope v)
   int EP = 0;
   if (e.gate.ptr) {
     const tem_view &g = e.gate;
