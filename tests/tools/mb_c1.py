@@ -42,3 +42,14 @@ gc0 = torch.randn(1, 130, 130, 130, 8, device=dev); dx = torch.empty(1, 132, 132
 l = H.conv_launch("bdc0", gc0, w, dx, 3, 1, 2, layout=H.TEM_W_FLIP_CO_CI)
 us = t([l]); nb = 4 * (8 * 130**3 + 132**3)
 print(f"{'bd.c0 8->1 @130':28s} {l.meta['kernel']:36s} {us:8.1f} us  {nb / us / 1e3:8.1f} GB/s", flush=True)
+# kernel gradients of the one-channel layers (bww_c1_k): g.bww.c0 (1 -> 8 @132), g.bww.f2 (16 -> 1 @98, swapped form), d.bww.d1a (1 -> 8 @96)
+from transfer_em_amd.models.params import ParamSet
+for name, ci, co, nin in (("bww.c0 1->8 @132", 1, 8, 132), ("bww.f2 16->1 @98", 16, 1, 98), ("bww.d1a 1->8 @96", 1, 8, 96)):
+    xx = torch.randn(1, nin, nin, nin, ci, device=dev); gg = torch.randn(1, nin - 2, nin - 2, nin - 2, co, device=dev)
+    P = ParamSet({"w": (3, 3, 3, ci, co)}, dev, seed=1)
+    ws = H.GradWorkspace(P, 1)
+    l = H.bww_launch(name, xx, gg, ws, "w", 0, 3, 1, 0)
+    red = ws.reduce_launches("r")
+    H.run([l] + red); torch.cuda.synchronize()
+    us = t([l]); nb = 4 * (ci * nin**3 + co * (nin - 2)**3)
+    print(f"{name:28s} {l.meta['kernel']:36s} {us:8.1f} us  {nb / us / 1e3:8.1f} GB/s", flush=True)
