@@ -94,15 +94,19 @@ __global__ __launch_bounds__(256) void bww_c1_k(C1Dev p) {
   };
   typedef float f4 __attribute__((ext_vector_type(4)));
   const uint32_t gaddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)(gring + tid * 4);
-  auto load_g = [&](int z) -> float4 {                       // the lane's chunk of plane z (fetched RING planes ago)
-    // counted wait + read in ONE asm statement: as a plain LDS load hipcc would put vmcnt(0) in front of it (it cannot
-    // count the DMA) and drain the ring every plane.  vmcnt(RING - 1): all but the newest RING - 1 fetches have landed.
-    f4 v;
+  // The lane's chunk of a plane is read one step AHEAD of its use (read_issue at the head of step z for plane z + 1,
+  // read_done at its tail): the LDS round trip runs under the step's 108 FMAs instead of in front of them.  Counted
+  // wait + read in ONE asm statement: as a plain LDS load hipcc would put vmcnt(0) in front of it (it cannot count the
+  // DMA) and drain the ring every plane.  vmcnt(N): all but the newest N fetches have landed.
+  auto read_first = [&](f4 &v, int z) {                     // plane z0: all RING fetches issued, the oldest must have landed
     asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(v) : "v"(gaddr + (uint32_t)(((z - z0) % RING) * 4096)), "n"(RING - 1) : "memory");
-    dma_g(z + RING);
-    return make_float4(v.x, v.y, v.z, v.w);
   };
+  auto read_issue = [&](f4 &v, int z) {                     // plane z = current + 1: fetches current + 2 .. current + RING - 1 may be in flight
+    asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b128 %0, %1"
+                 : "=&v"(v) : "v"(gaddr + (uint32_t)(((z - z0) % RING) * 4096)), "n"(RING - 2) : "memory");
+  };
+  auto read_done = [&](f4 &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory"); };
 #pragma unroll
   for (int k = 0; k < RING; ++k) dma_g(z0 + k);
   auto load_w = [&](float (&w)[9], int zz) {                  // the 3x3 X neighbours of the lane's column in staged plane zz
@@ -125,47 +129,64 @@ __global__ __launch_bounds__(256) void bww_c1_k(C1Dev p) {
   // staged planes zi, zi + 1, zi + 2 (taps dz = 0, 1, 2) with G[z0 + zi]; G is fetched one plane ahead
   float w0[9], w1[9], w2[9];
   load_w(w0, 0); load_w(w1, 1);
+  f4 ga, gb, gc;
+  read_first(ga, z0);
+  auto G4 = [](const f4 &v) { return make_float4(v.x, v.y, v.z, v.w); };
   for (int zi = 0; zi < nz; zi += 3) {
     {
+      read_issue(gb, z0 + zi + 1); dma_g(z0 + zi + RING);
       load_w(w2, zi + 2);
-      const float4 gc = load_g(z0 + zi);
-      fma_plane(w0, 0, gc); fma_plane(w1, 1, gc); fma_plane(w2, 2, gc);
+      const float4 g = G4(ga);
+      fma_plane(w0, 0, g); fma_plane(w1, 1, g); fma_plane(w2, 2, g);
+      read_done(gb);
     }
     if (zi + 1 < nz) {
+      read_issue(gc, z0 + zi + 2); dma_g(z0 + zi + 1 + RING);
       load_w(w0, zi + 3);
-      const float4 gc = load_g(z0 + zi + 1);
-      fma_plane(w1, 0, gc); fma_plane(w2, 1, gc); fma_plane(w0, 2, gc);
+      const float4 g = G4(gb);
+      fma_plane(w1, 0, g); fma_plane(w2, 1, g); fma_plane(w0, 2, g);
+      read_done(gc);
     }
     if (zi + 2 < nz) {
+      read_issue(ga, z0 + zi + 3); dma_g(z0 + zi + 2 + RING);
       load_w(w1, zi + 4);
-      const float4 gc = load_g(z0 + zi + 2);
-      fma_plane(w2, 0, gc); fma_plane(w0, 1, gc); fma_plane(w1, 2, gc);
+      const float4 g = G4(gc);
+      fma_plane(w2, 0, g); fma_plane(w0, 1, g); fma_plane(w1, 2, g);
+      read_done(ga);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the ring's tail fetches (zeros) before the LDS is reused
 
-  // ---- sum over the lanes that share a channel quad (butterfly over lane bits >= log2 NQ), then over the waves via LDS
-  __syncthreads();                                            // the LDS is reused as the cross-wave buffer
+  // ---- sum over the lanes that share a channel quad.  Within a row of 16 lanes: DPP row shifts by multiples of NQ (they keep
+  // lane % NQ; vector-pipe speed -- as a __shfl_xor butterfly this was 540 ds_bpermute + 206 waits per wave, about as long as
+  // the whole march); the last NQ lanes of each row then hold the row's sums.  Rows and waves: through LDS, fixed order.
+  __syncthreads();                                            // the LDS is reused as the cross-row / cross-wave buffer
 #pragma unroll
   for (int t = 0; t < 27; ++t)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float v = acc[t][c];
-#pragma unroll
-      for (int o = 32; o >= NQ; o >>= 1) v += __shfl_xor(v, o, 64);
+      // row_shr:o for o = NQ, 2 NQ, .. 8 (zeros shifted in)
+      if (NQ <= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
       acc[t][c] = v;
     }
-  float *red = smem;                                          // [4 waves][27][CO]
-  if (lane < NQ) {
+  float *red = smem;                                          // [4 waves x 4 rows][27][CO]
+  if ((lane & 15) >= 16 - NQ) {
+    const int part = wave * 4 + (lane >> 4), q4 = (lane & 15) - (16 - NQ);
 #pragma unroll
     for (int t = 0; t < 27; ++t)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) red[(wave * 27 + t) * CO + 4 * lane + c] = acc[t][c];
+      *reinterpret_cast<float4 *>(red + (part * 27 + t) * CO + 4 * q4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
   }
   __syncthreads();
   float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride;
-  for (int i = tid; i < 27 * CO; i += 256)
-    slab[i] = (red[i] + red[27 * CO + i]) + (red[2 * 27 * CO + i] + red[3 * 27 * CO + i]);
+  for (int i = tid; i < 27 * CO; i += 256) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k * 27 * CO + i];
+    slab[i] = v;
+  }
 }
 
 static int run(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out, char *name, int name_len) {
