@@ -42,8 +42,30 @@ def _ndhwc(t):
     return np.moveaxis(t.detach().numpy(), 1, -1)
 
 
-def _lr(x, a=ALPHA):
-    return torch.where(x > 0, x, a * x)
+class _GatedLeaky(torch.autograd.Function):
+    """LeakyReLU whose backward takes its branch from a slot that may be re-bound between forward and backward
+    (gate alignment of the parity tests, see graph._gate_on): slot["pos"] is the forward's own x > 0 unless replaced."""
+
+    @staticmethod
+    def forward(ctx, x, a, slot):
+        pos = x > 0
+        slot.setdefault("pos", pos)
+        ctx.slot, ctx.a = slot, a
+        return torch.where(pos, x, a * x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.where(ctx.slot["pos"], g, ctx.a * g), None, None
+
+
+def _lr(x, a=ALPHA, rec=None, key=None):
+    """rec: dict receiving key -> {"out": activation, "pos": branch taken in backward} (None: plain autograd)."""
+    if rec is None:
+        return torch.where(x > 0, x, a * x)
+    slot = rec.setdefault(key, {})
+    y = _GatedLeaky.apply(x, a, slot)
+    slot["out"] = y.detach()
+    return y
 
 
 def _st(is3d, s):
@@ -61,28 +83,29 @@ def _zpad(t, p, is3d):
     return F.pad(t, (p, p, p, p, p, p) if is3d else (p, p, p, p, 0, 0))
 
 
-def generator(P, x, is3d=True, keep=None):
-    """x NCDHW.  keep = (k2, k1) dropout multipliers (NCDHW tensors of 0/2) or None (inference)."""
-    a0 = _lr(F.conv3d(x, _w(P["c0"])))
-    s0 = _lr(F.conv3d(a0, _w(P["d1a"])))
-    d1 = _lr(F.conv3d(s0, _w(P["d1b"]), stride=_st(is3d, 2)))
-    s1 = _lr(F.conv3d(d1, _w(P["d2a"])))
-    d2 = _lr(F.conv3d(s1, _w(P["d2b"]), stride=_st(is3d, 2)))
-    b2 = _lr(F.conv3d(d2, _w(P["u2a"])))
+def generator(P, x, is3d=True, keep=None, rec=None):
+    """x NCDHW.  keep = (k2, k1) dropout multipliers (NCDHW tensors of 0/2) or None (inference).
+    rec: optional dict receiving the LeakyReLU slots under graph.generator_forward's saved keys."""
+    a0 = _lr(F.conv3d(x, _w(P["c0"])), ALPHA, rec, "a0")
+    s0 = _lr(F.conv3d(a0, _w(P["d1a"])), ALPHA, rec, "s0")
+    d1 = _lr(F.conv3d(s0, _w(P["d1b"]), stride=_st(is3d, 2)), ALPHA, rec, "d1")
+    s1 = _lr(F.conv3d(d1, _w(P["d2a"])), ALPHA, rec, "s1")
+    d2 = _lr(F.conv3d(s1, _w(P["d2b"]), stride=_st(is3d, 2)), ALPHA, rec, "d2")
+    b2 = _lr(F.conv3d(d2, _w(P["u2a"])), ALPHA, rec, "b2")
     pT = (1, 1, 1) if is3d else (0, 1, 1)
     c2 = F.conv_transpose3d(b2, _wT(P["u2b"]), stride=_st(is3d, 2), padding=pT)
     if keep is not None:
         c2 = c2 * keep[0]
-    u2 = _lr(c2)
+    u2 = _lr(c2, ALPHA, rec, "u2")
     lo, hi = graph.skip_crop(s1.shape[-1], u2.shape[-1])
-    m = _lr(F.conv3d(torch.cat([u2, _crop(s1, lo, hi, is3d)], 1), _w(P["mid"])))
-    b1 = _lr(F.conv3d(m, _w(P["u1a"])))
+    m = _lr(F.conv3d(torch.cat([u2, _crop(s1, lo, hi, is3d)], 1), _w(P["mid"])), ALPHA, rec, "m")
+    b1 = _lr(F.conv3d(m, _w(P["u1a"])), ALPHA, rec, "b1")
     c1 = F.conv_transpose3d(b1, _wT(P["u1b"]), stride=_st(is3d, 2), padding=pT)
     if keep is not None:
         c1 = c1 * keep[1]
-    u1 = _lr(c1)
+    u1 = _lr(c1, ALPHA, rec, "u1")
     lo, hi = graph.skip_crop(s0.shape[-1], u1.shape[-1])
-    f1 = _lr(F.conv3d(torch.cat([u1, _crop(s0, lo, hi, is3d)], 1), _w(P["f1"])))
+    f1 = _lr(F.conv3d(torch.cat([u1, _crop(s0, lo, hi, is3d)], 1), _w(P["f1"])), ALPHA, rec, "f1")
     return F.conv3d(f1, _w(P["f2"]))
 
 
@@ -98,20 +121,22 @@ def prior_features(prior, x, is3d=True):
     return h
 
 
-def discriminator(P, x, is3d=True, prior=None):
+def discriminator(P, x, is3d=True, prior=None, rec=None):
+    """rec: optional dict receiving the LeakyReLU slots under graph.discriminator_forward's saved keys."""
     if is3d:
-        e1 = _lr(F.conv3d(x, _w(P["d1a"])))
-        e2 = _lr(F.conv3d(e1, _w(P["d1b"]), stride=_st(is3d, 2)))
-        h = _lr(F.conv3d(e2, _w(P["hack"])))
+        e1 = _lr(F.conv3d(x, _w(P["d1a"])), ALPHA, rec, "e1")
+        e2 = _lr(F.conv3d(e1, _w(P["d1b"]), stride=_st(is3d, 2)), ALPHA, rec, "e2")
+        h = _lr(F.conv3d(e2, _w(P["hack"])), ALPHA, rec, "h")
     else:
-        h = _lr(F.conv3d(x, _w(P["hack"])))
-    e3 = _lr(F.conv3d(h, _w(P["d2a"])))
-    e4 = _lr(F.conv3d(e3, _w(P["d2b"]), stride=_st(is3d, 2)))
+        h = _lr(F.conv3d(x, _w(P["hack"])), ALPHA, rec, "h")
+    e3 = _lr(F.conv3d(h, _w(P["d2a"])), ALPHA, rec, "e3")
+    e4 = _lr(F.conv3d(e3, _w(P["d2b"]), stride=_st(is3d, 2)), ALPHA, rec, "e4")
     if prior is not None:
         e4 = torch.cat([e4, prior_features(prior, x, is3d)], 1)          # discriminator.py:62-66
-    e5 = _lr(F.conv3d(e4, _w(P["d3a"])))
-    e6 = _lr(_lr(F.conv3d(e5, _w(P["d3b"]), stride=_st(is3d, 2))))
-    p1 = _lr(F.conv3d(e6, _w(P["p1"])))
+    e5 = _lr(F.conv3d(e4, _w(P["d3a"])), ALPHA, rec, "e5")
+    # lrelu(lrelu(.)) (models/utils.py:83 then discriminator.py:74): one slot, slope 0.3 * 0.3 on the negative branch
+    e6 = _lr(F.conv3d(e5, _w(P["d3b"]), stride=_st(is3d, 2)), ALPHA * ALPHA, rec, "e6")
+    p1 = _lr(F.conv3d(e6, _w(P["p1"])), ALPHA, rec, "p1")
     return F.conv3d(p1, _w(P["p2"]), bias=P["p2_bias"])
 
 
@@ -165,31 +190,45 @@ def _keeps(real_shape_ndhwc, P, call_id, seed, step, is3d, dtype):
 
 
 def train_step_grads(Pg, Pf, Pdx, Pdy, real_x, real_y, is3d=True, gamma=2.0, seed=42, step=0,
-                     dtype=torch.float64, literal=True, prior_y=None):
+                     dtype=torch.float64, literal=True, prior_y=None, gates=None):
     """cgan.py:144-215 on autograd.  literal=True issues the reference's four gradient
-    calls; literal=False uses the 2-sweep equivalent (the timed baseline).  NDHWC numpy in."""
+    calls; literal=False uses the 2-sweep equivalent (the timed baseline).  NDHWC numpy in.
+    gates: as graph.train_step_grads -- callable(saved) -> {call: {key: bool NDHWC array}} evaluated between the
+    forward and the gradient calls; every listed LeakyReLU then differentiates the given branch.  With gates the
+    saved activations come back as aux["saved"] (NDHWC views)."""
     tg, tf_, tdx, tdy = (to_torch(p, dtype) for p in (Pg, Pf, Pdx, Pdy))
     return _step_core(tg, tf_, tdx, tdy, _ncdhw(real_x, dtype), _ncdhw(real_y, dtype),
-                      np.asarray(real_x).shape, is3d, gamma, seed, step, dtype, literal, prior_y)
+                      np.asarray(real_x).shape, is3d, gamma, seed, step, dtype, literal, prior_y, gates)
 
 
-def _step_core(tg, tf_, tdx, tdy, rx, ry, shape_ndhwc, is3d, gamma, seed, step, dtype, literal, prior_y=None):
+def _step_core(tg, tf_, tdx, tdy, rx, ry, shape_ndhwc, is3d, gamma, seed, step, dtype, literal, prior_y=None, gates=None):
     n = shape_ndhwc[3]
     b = (n - graph.generator_out(n)) // 2
     K = lambda call, P: _keeps(shape_ndhwc, P, call, seed, step, is3d, dtype)
     cr = lambda t, c: _crop(t, c, c, is3d)
 
-    fake_y = generator(tg, rx, is3d, K(graph.CALL_G_FAKE_Y, tg))
-    cyc_x = generator(tf_, _zpad(fake_y, b, is3d), is3d, K(graph.CALL_F_CYC_X, tf_))
-    fake_x = generator(tf_, ry, is3d, K(graph.CALL_F_FAKE_X, tf_))
-    cyc_y = generator(tg, _zpad(fake_x, b, is3d), is3d, K(graph.CALL_G_CYC_Y, tg))
-    same_x = generator(tf_, rx, is3d, K(graph.CALL_F_SAME_X, tf_))
-    same_y = generator(tg, ry, is3d, K(graph.CALL_G_SAME_Y, tg))
+    calls = ("g1", "f2", "f1", "g2", "f3", "g3", "dxr", "dyr", "dxf", "dyf")
+    rec = {c: ({} if gates is not None else None) for c in calls}
+    fake_y = generator(tg, rx, is3d, K(graph.CALL_G_FAKE_Y, tg), rec["g1"])
+    cyc_x = generator(tf_, _zpad(fake_y, b, is3d), is3d, K(graph.CALL_F_CYC_X, tf_), rec["f2"])
+    fake_x = generator(tf_, ry, is3d, K(graph.CALL_F_FAKE_X, tf_), rec["f1"])
+    cyc_y = generator(tg, _zpad(fake_x, b, is3d), is3d, K(graph.CALL_G_CYC_Y, tg), rec["g2"])
+    same_x = generator(tf_, rx, is3d, K(graph.CALL_F_SAME_X, tf_), rec["f3"])
+    same_y = generator(tg, ry, is3d, K(graph.CALL_G_SAME_Y, tg), rec["g3"])
 
-    z_rx = discriminator(tdx, cr(rx, b), is3d)
-    z_ry = discriminator(tdy, cr(ry, b), is3d, prior_y)
-    z_fx = discriminator(tdx, fake_x, is3d)
-    z_fy = discriminator(tdy, fake_y, is3d, prior_y)
+    z_rx = discriminator(tdx, cr(rx, b), is3d, rec=rec["dxr"])
+    z_ry = discriminator(tdy, cr(ry, b), is3d, prior_y, rec=rec["dyr"])
+    z_fx = discriminator(tdx, fake_x, is3d, rec=rec["dxf"])
+    z_fy = discriminator(tdy, fake_y, is3d, prior_y, rec=rec["dyf"])
+
+    saved = None
+    if gates is not None:
+        saved = {c: {k: _ndhwc(slot["out"]) for k, slot in rec[c].items()} for c in calls}
+        for c, g in gates(saved).items():
+            for k, pos in g.items():
+                t = torch.from_numpy(np.ascontiguousarray(np.moveaxis(np.asarray(pos, dtype=bool), -1, 1)))
+                assert t.shape == rec[c][k]["pos"].shape, (c, k, t.shape, rec[c][k]["pos"].shape)
+                rec[c][k]["pos"] = t
 
     gen_g = generator_loss(z_fy, gamma)
     gen_f = generator_loss(z_fx, gamma)
@@ -216,7 +255,7 @@ def _step_core(tg, tf_, tdx, tdy, rx, ry, shape_ndhwc, is3d, gamma, seed, step, 
     name = lambda P, g: OrderedDict((k, gi.detach().numpy()) for k, gi in zip(P.keys(), g))
     grads = dict(g=name(tg, g_g), f=name(tf_, g_f), dx=name(tdx, g_dx), dy=name(tdy, g_dy))
     aux = dict(fake_y=_ndhwc(fake_y), fake_x=_ndhwc(fake_x), cyc_x=_ndhwc(cyc_x), cyc_y=_ndhwc(cyc_y),
-               same_x=_ndhwc(same_x), same_y=_ndhwc(same_y), z_fy=_ndhwc(z_fy), z_rx=_ndhwc(z_rx))
+               same_x=_ndhwc(same_x), same_y=_ndhwc(same_y), z_fy=_ndhwc(z_fy), z_rx=_ndhwc(z_rx), saved=saved)
     return losses, grads, aux
 
 

@@ -49,7 +49,7 @@ def _flat(d):
     return np.concatenate([np.asarray(v, np.float64).ravel() for v in d.values()])
 
 
-@pytest.mark.parametrize("is3d", [False])
+@pytest.mark.parametrize("is3d", [False, True])
 def test_two_rank_step_matches_oracle(tmp_path, rank_launcher, oracle_lib, is3d):
     res = rank_launcher([sys.executable, os.path.join(ROOT, "tests", "tools", "dp_rank.py"), str(tmp_path)] +
                         (["3d"] if is3d else []), ranks=2, timeout=900)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import gate_flips, hip_gates, rel_err, scaled_params
+from util import activation_stats, hip_gates, rel_err, scaled_params
 
 pytestmark = pytest.mark.gpu
 
@@ -64,9 +64,12 @@ def test_train_step_matches_oracle(tmp_path, oracle_lib, is3d, batch, scaled):
                           ("same_y", "g3")):
             ref = crop(aux[key]) if key.startswith("cyc") else aux[key]      # cycled_*: only the cropped window exists
             assert rel_err(cs.fwd[plan].y.cpu().numpy(), ref) < 1e-4, key
-        flips = gate_flips(cs, aux["saved"], is3d)          # diagnostic only (pre-activations within rounding of 0)
+        # every saved activation of the ten call sites against the oracle's, and a bound on the gate flips (pre-activations
+        # within rounding of 0): the gate alignment above must not be able to hide a wrong forward kernel
+        flips, total, worst, where = activation_stats(cs, aux["saved"], is3d, tol=1e-4)
         gtol = 2e-4 if is3d else 1e-4
-        print(f"step {step}: {flips} gate flips (aligned), gradient tolerance {gtol:g}")
+        print(f"step {step}: {flips} gate flips of {total} activations (aligned), worst activation error {worst:.1e} at "
+              f"{where}, gradient tolerance {gtol:g}")
         assert rel_err(cs.bwd["f2"].dx.cpu().numpy(), aux["d_fake_y"]) < gtol
         for net in ("g", "f", "dx", "dy"):
             for name, ref in grads[net].items():
@@ -114,14 +117,53 @@ def test_train_step_3d_batch2_one_step(tmp_path, oracle_lib):
     assert rel_err(got, losses) < 1e-5
     for key, plan in (("fake_y", "g1"), ("fake_x", "f1"), ("same_x", "f3"), ("same_y", "g3")):
         assert rel_err(cs.fwd[plan].y.cpu().numpy(), aux[key]) < 1e-4, key
-    flips = gate_flips(cs, aux["saved"], True)
+    flips, total, worst, where = activation_stats(cs, aux["saved"], True, tol=1e-4)
     gtol = 2e-4                                             # unconditional: the oracle backward uses the HIP gates
-    print(f"{flips} gate flips (aligned), gradient tolerance {gtol:g}")
+    print(f"{flips} gate flips of {total} (aligned), worst activation error {worst:.1e} at {where}, gradient tolerance {gtol:g}")
     for net in ("g", "f", "dx", "dy"):
         scale = max(np.abs(v).max() for v in grads[net].values())
         for name, ref in grads[net].items():
             err = np.abs(grads_hip[net][name] - ref).max()
             assert err <= gtol * np.abs(ref).max() + 1e-7 * scale + 3e-8, (net, name, err)
+
+
+def test_train_step_132_matches_oracle(tmp_path):
+    """BASELINE configs[1] itself -- 3-D 132^3, batch 1, fp32 -- against oracle/torch_ref.py in float64 (literal
+    transcription of cgan.py:144-230 on PyTorch-CPU autograd, four gradient calls): the 7 losses to 1e-5, the six
+    generator outputs and every saved activation of the ten call sites to 1e-4, every kernel gradient to 2e-4 of its
+    largest entry (LeakyReLU branches aligned with the HIP forward, flips counted and bounded).  This is the only place
+    where the step's own kernel variants (Winograd epilogues with gate / keep bits / split outputs, cone windows, the
+    k4 s2 split-K forms, the C = 1 kernels) meet the oracle at the shapes the benchmark runs."""
+    from oracle import graph, torch_ref
+    from transfer_em_amd.cgan import EM2EM
+    n = 132
+    shape = (1, n, n, n, 1)
+    rx, ry = _inputs(shape, 1234), _inputs(shape, 5678)
+    st = _state(graph, True, True)
+    model = EM2EM(n, "parity132", seed=42, checkpoint_root=str(tmp_path))
+    _load(model, st)
+    assert model.outdimsize == 96 and model.buffer == 18
+    got = model.train_step(torch.from_numpy(rx), torch.from_numpy(ry)).cpu().numpy()
+    cs = model._steps[1]
+    grads_hip = {k: net.params.to_dict("grad") for k, net in zip(("g", "f", "dx", "dy"), model._nets)}
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    losses, grads, aux = torch_ref.train_step_grads(st["g"], st["f"], st["dx"], st["dy"], rx, ry, True, 2.0, 42, 0,
+                                                    gates=hip_gates(cs, True))
+    assert rel_err(got, losses) < 1e-5, (got, losses)
+    b = model.buffer
+    crop = lambda t: t[:, b:-b, b:-b, b:-b, :]
+    for key, plan in (("fake_y", "g1"), ("cyc_x", "f2"), ("fake_x", "f1"), ("cyc_y", "g2"), ("same_x", "f3"), ("same_y", "g3")):
+        ref = crop(aux[key]) if key.startswith("cyc") else aux[key]
+        assert rel_err(cs.fwd[plan].y.cpu().numpy(), ref) < 1e-4, key
+    flips, total, worst, where = activation_stats(cs, aux["saved"], True, tol=1e-4)
+    print(f"132^3: {flips} gate flips of {total} activations (aligned), worst activation error {worst:.1e} at {where}")
+    gtol = 2e-4
+    for net in ("g", "f", "dx", "dy"):
+        scale = max(np.abs(v).max() for v in grads[net].values())
+        for name, ref in grads[net].items():
+            err = np.abs(grads_hip[net][name] - ref).max()
+            floor = 1e-7 * scale + (3e-8 if name.endswith("_bias") else 0.0)
+            assert err <= gtol * np.abs(ref).max() + floor, (net, name, err, np.abs(ref).max())
 
 
 def test_graph_replay_equals_eager(tmp_path):

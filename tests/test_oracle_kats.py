@@ -137,6 +137,44 @@ def test_hand_backward_matches_autograd_2d(oracle_lib):
             assert np.abs(np.asarray(G[net][k]) - G2[net][k]).max() < 2e-5 * np.abs(G2[net][k]).max() + 1e-7 * scale, (net, k)
 
 
+def test_gate_hook_agrees_between_restatements(oracle_lib):
+    """The gate-alignment hook (LeakyReLU branches handed in between forward and backward) means the same thing in
+    oracle/graph.py and oracle/torch_ref.py: with the same perturbed branches both give the same gradients, and these
+    differ from the unperturbed ones (the hook is live)."""
+    from oracle import torch_ref
+    from util import scaled_params
+    rng = np.random.default_rng(3)
+    rx = rng.standard_normal((1, 1, 74, 74, 1)).astype(np.float32)
+    ry = rng.standard_normal((1, 1, 74, 74, 1)).astype(np.float32)
+    gs, ds = graph.generator_param_shapes(False), graph.discriminator_param_shapes(False)
+    P = [scaled_params(gs, 1), scaled_params(gs, 2), scaled_params(ds, 3), scaled_params(ds, 4)]
+
+    def flip_some(saved):
+        r = np.random.default_rng(7)
+        out = {}
+        for call, sv in saved.items():
+            g = {}
+            for key in ("s0", "m", "u1", "e3", "e6"):
+                if key in sv and hasattr(sv[key], "shape"):
+                    pos = np.asarray(sv[key]) > 0
+                    g[key] = pos ^ (r.random(pos.shape) < 0.01)
+            out[call] = g
+        return out
+
+    L0, G0, _ = graph.train_step_grads(*P, rx, ry, False)
+    L1, G1, _ = graph.train_step_grads(*P, rx, ry, False, gates=flip_some)
+    L2, G2, aux2 = torch_ref.train_step_grads(*P, rx, ry, False, gates=flip_some)
+    assert np.abs(L1 - L2).max() < 1e-6 * np.abs(L2).max() and set(aux2["saved"]) == set(
+        ("g1", "f2", "f1", "g2", "f3", "g3", "dxr", "dyr", "dxf", "dyf"))
+    live = 0.0
+    for net in ("g", "f", "dx", "dy"):
+        scale = max(np.abs(v).max() for v in G2[net].values())
+        for k in G1[net]:
+            assert np.abs(np.asarray(G1[net][k]) - G2[net][k]).max() < 2e-5 * np.abs(G2[net][k]).max() + 1e-7 * scale, (net, k)
+            live = max(live, np.abs(np.asarray(G1[net][k]) - np.asarray(G0[net][k])).max() / scale)
+    assert live > 1e-3
+
+
 @pytest.mark.parametrize("tag,is3d,batch,scaled", [("step2d_74_scaled_b2", False, 2, True),
                                                    ("step2d_74_refinit_b1", False, 1, False)])
 def test_oracle_reproduces_golden(oracle_lib, tag, is3d, batch, scaled):
@@ -180,3 +218,30 @@ def test_instance_norm_kat():
     for idx in [(0, 0, 0, 0, 0), (1, 2, 3, 4, 1), (0, 1, 2, 3, 1)]:
         e = np.zeros_like(x); e[idx] = 1e-6
         assert np.isclose((f(x + e) - f(x - e)) / 2e-6, dx[idx], rtol=1e-5, atol=1e-8)
+
+
+def test_torch_ops_agree_with_c_oracle(oracle_lib):
+    """oracle/torch_ops.py (float64 PyTorch-CPU, used at the benchmark's full sizes) == oracle/ops.py (scalar C loops)
+    for every operator and adjoint the full-size tests use, incl. strides, padding and odd edges."""
+    from oracle import torch_ops as T
+    rng = np.random.default_rng(0)
+    r = lambda *s: rng.standard_normal(s).astype(np.float32)
+    close = lambda a, b: np.abs(np.asarray(a, np.float64) - b).max() <= 2e-6 * np.abs(b).max()
+    x, w = r(2, 9, 10, 11, 5), r(3, 3, 3, 5, 7)
+    for pad in (0, 2):
+        y = T.conv_fwd(x, w, 1, pad)
+        assert close(oracle_lib.conv_fwd(x, w, 1, pad), y)
+        g = r(*y.shape)
+        assert close(oracle_lib.conv_bwd_data(g, w, x.shape, 1, pad), T.conv_bwd_data(g, w, x.shape, 1, pad))
+        assert close(oracle_lib.conv_bwd_weight(x, g, (3, 3, 3), 1, pad), T.conv_bwd_weight(x, g, (3, 3, 3), 1, pad))
+    x, w = r(1, 11, 12, 13, 4), r(4, 4, 4, 4, 6)            # k4 s2 VALID, odd edges (last voxel untouched)
+    y = T.conv_fwd(x, w, 2, 0)
+    g = r(*y.shape)
+    assert close(oracle_lib.conv_fwd(x, w, 2, 0), y)
+    assert close(oracle_lib.conv_bwd_data(g, w, x.shape, 2, 0), T.conv_bwd_data(g, w, x.shape, 2, 0))
+    assert close(oracle_lib.conv_bwd_weight(x, g, (4, 4, 4), 2, 0), T.conv_bwd_weight(x, g, (4, 4, 4), 2, 0))
+    x, w = r(1, 5, 6, 7, 6), r(4, 4, 4, 3, 6)               # transposed convolution, kernel (k,k,k,CO,CI)
+    y = T.convT_fwd(x, w)
+    assert y.shape == (1, 10, 12, 14, 3) and close(oracle_lib.convT_fwd(x, w), y)
+    g = r(*y.shape)
+    assert close(oracle_lib.convT_bwd_data(g, w, x.shape), T.convT_bwd_data(g, w, x.shape))

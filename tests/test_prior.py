@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import gate_flips, hip_gates, prior_layers, rel_err, scaled_params
+from util import activation_stats, hip_gates, prior_layers, rel_err, scaled_params
 
 
 def _chain(layers, cut):
@@ -129,9 +129,9 @@ def test_train_step_with_disc_prior(tmp_path, oracle_lib):
     losses, grads, aux = graph.train_step(st, rx, ry, False, 2.0, 42, prior_y=chain,
                                           gates=hip_gates(model._steps[2], False))
     assert rel_err(got, losses) < 1e-5
-    flips = gate_flips(model._steps[2], aux["saved"], False)
+    flips, total, worst, where = activation_stats(model._steps[2], aux["saved"], False, tol=1e-4)
     gtol = 1e-4                                   # unconditional: the oracle backward uses the HIP gates (util.hip_gates)
-    print(f"{flips} gate flips (aligned), gradient tolerance {gtol:g}")
+    print(f"{flips} gate flips of {total} (aligned), worst activation error {worst:.1e} at {where}, gradient tolerance {gtol:g}")
     for net in ("g", "f", "dx", "dy"):
         scale = max(np.abs(v).max() for v in grads[net].values())
         for name, ref in grads[net].items():

@@ -46,20 +46,42 @@ def gate_flips(cs, saved, is3d=True):
     and the difference spreads to every kernel gradient below it.  One flip among ~10^6 elements already
     shows as ~1e-4..1e-3 relative error, so the step-level gradient tolerance is tight only when this
     returns 0.  `cs` is the compiled step (cgan._CompiledStep), `saved` is aux["saved"] of the oracle."""
-    n = 0
+    return activation_stats(cs, saved, is3d)[0]
+
+
+FLIP_BOUND = 1e-5       # gate flips allowed per compared activation (measured: ~1e-6, pre-activations within rounding of 0)
+
+
+def activation_stats(cs, saved, is3d=True, tol=None):
+    """(gate flips, compared elements, worst relative activation error, its (call, layer)) over every saved LeakyReLU
+    output of the step: the HIP forward's activation buffers against the oracle's (on the evaluated region for the
+    cycle-path call sites).  With `tol` every activation is asserted to it (relative to the tensor's largest value)
+    and the flip count to FLIP_BOUND of the compared elements -- so a forward kernel that is wrong on small activations
+    cannot hide behind the gate alignment of the backward comparison."""
+    n = total = 0
+    worst, where = 0.0, None
     for call, sv in saved.items():
         fwd = cs.fwd[call]
         table = _GEN_SAVED if call[0] in "gf" else _DISC_SAVED
         for layer, key in table.items():
             if key not in sv or layer not in fwd.act:
                 continue
-            ref = sv[key]
+            ref = np.asarray(sv[key])
             if call[0] in "gf":
                 lo, hi = fwd.regions[layer]
                 ref = ref[:, lo:hi, lo:hi, lo:hi, :] if is3d else ref[:, :, lo:hi, lo:hi, :]
             got = fwd.act[layer].float().cpu().numpy()
+            assert got.shape == ref.shape, (call, layer, got.shape, ref.shape)
             n += int(np.count_nonzero((got > 0) != (ref > 0)))
-    return n
+            total += got.size
+            e = rel_err(got, ref)
+            if e > worst:
+                worst, where = e, (call, layer)
+            if tol is not None:
+                assert e < tol, (call, layer, e)
+    if tol is not None:
+        assert n <= max(2, FLIP_BOUND * total), (n, total)
+    return n, total, worst, where
 
 
 def hip_gates(cs, is3d=True):
