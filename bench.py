@@ -3,6 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
 
+With --gpus N > 1 outside torch.distributed.run the script starts `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` itself as a CHILD process (before touching the GPU), relays rank 0's JSON line and exits with the child's
+status; under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one rank of the job.
+
 A "step" is one EM2EM.train_step (6 generator forwards, 4 discriminator forwards, 10 loss
 terms, all input/kernel gradients, gradient all-reduce for N > 1, 4 Adam updates) on
 synthetic uint8-derived volumes already resident in HBM.  N > 1 is launched by
@@ -27,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0        # MI355X_MICROARCH.md: measured device copy rate (read + write streams)
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 RIDGE = FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
@@ -72,11 +77,55 @@ def per_kernel_profile(model, st, steps, streams=True):
     return agg
 
 
+def self_launch(argv, nproc):
+    """--gpus N > 1 without a launcher: run the N-rank job as a child (`python -m torch.distributed.run`, one process per
+    GPU, rendezvous on 127.0.0.1), pass its stderr through, print the ONE JSON line rank 0 wrote and return the child's
+    exit status.  Called before anything touches the GPU; the child is a subprocess, never an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in child.stdout.splitlines() if l.startswith("{") and l.rstrip().endswith("}")]
+    for l in child.stdout.splitlines():
+        if l not in lines[-1:]:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif child.returncode == 0:
+        print("bench.py: the launched job printed no JSON line", file=sys.stderr)
+        return 1
+    return child.returncode
+
+
+def dry_dist(args, world, rank):
+    """--dry-dist: the launch / rendezvous / reduce / one-line protocol of an N-rank run without the GPU (host test of the
+    launcher path with TEM_DIST_BACKEND=gloo): barrier, MAX-reduced time of a trivial loop, rank 0 prints the line."""
+    import torch.distributed as dist
+    dist.init_process_group(os.environ.get("TEM_DIST_BACKEND", "gloo"))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "value": args.steps * world / float(t.item()), "unit": "steps/s"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
     ap.add_argument("--dimsize", type=int, default=132)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,14 +142,18 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="run the step on one stream (kernel durations free of overlap: use under rocprofv3 to "
                          "check roofline.avg_launch_us)")
+    ap.add_argument("--dry-dist", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_dist:
+        return dry_dist(args, world, rank)
     ndev = max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank % ndev)           # (rehearsals put several ranks on one card)
     # TEM_DP_FORCE_EXCHANGE=1 under torch.distributed.run with one rank: a process group of one that still issues
@@ -198,16 +251,27 @@ def main():
             roof["executed_mfma_frac"] = roof["achieved"] / 2.25 / roof["peak"]
         # HBM bytes per launch of this kernel from the PMC passes of profiles/collect_round.sh (the counters cannot
         # be read inside this process): average over the same launches of the train step that `achieved` averages
-        # over; null if the kernel has not been profiled
+        # over.  The tables are stamped with a digest of the kernel sources they were collected on: null when the
+        # sources of this run differ (a stale table is worse than none) or the kernel has not been profiled.
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from collect_traffic import csrc_digest
+        digest = csrc_digest()
+
+        def table(name):
+            try:
+                t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            except (OSError, ValueError):
+                return {}
+            return t if t.get("_meta", {}).get("csrc_digest") == digest else {}
+        traffic, mfma = table("hbm_traffic.json"), table("mfma_busy.json")
+        roof["counters_match_sources"] = bool(traffic)
         roof["traffic"] = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            key = dom_k.split("(")[0]
-            if key in tr:
-                roof["traffic"] = tr[key]["hbm_bytes_per_launch"]
-                roof["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["launches"]
-        except (OSError, ValueError):
-            pass
+        key = dom_k.split("(")[0]
+        if key in traffic:
+            roof["traffic"] = traffic[key]["hbm_bytes_per_launch"]
+            roof["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["launches"]
+        # share of the launch with the matrix pipes busy (SQ_VALU_MFMA_BUSY_CYCLES pass, profiles/collect_mfma.py)
+        roof["mfma_busy"] = mfma[key]["mfma_busy"] if key in mfma else None
         roof["kernel"] = dom_k
         roof["avg_launch_us"] = dom["ms"] * 1e3 / dom["launches"]
         roof["share_of_step"] = dom["ms"] / sum(v["ms"] for v in agg.values())
@@ -222,21 +286,20 @@ def main():
                               "achieved_gbs": tot_bytes / (dt / args.steps) / 1e9,
                               "hbm_frac": tot_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                               "standalone_kernel_ms_per_step": sum(v["ms"] for v in agg.values()) / nprof}
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-        except (OSError, ValueError):
-            traffic = {}
         fam = {}
         for k, v in agg.items():
-            f = fam.setdefault(k.split("<")[0], dict(ms=0.0, flops=0.0, bytes=0.0, counter=0.0, counter_alg=0.0))
+            f = fam.setdefault(k.split("<")[0], dict(ms=0.0, flops=0.0, bytes=0.0, counter=0.0, counter_alg=0.0, busy=0.0, busy_ms=0.0))
             f["ms"] += v["ms"]; f["flops"] += v["flops"]; f["bytes"] += v["bytes"]
             if k in traffic and v["bytes"] > 0:            # PMC passes of profiles/collect_round.sh, same launches
                 f["counter"] += traffic[k]["hbm_bytes_per_launch"] * v["launches"]
                 f["counter_alg"] += v["bytes"]
+            if k in mfma and mfma[k]["mfma_busy"] is not None:
+                f["busy"] += mfma[k]["mfma_busy"] * v["ms"]; f["busy_ms"] += v["ms"]
         roof["classes"] = {
             name: {"ms_per_step": f["ms"] / nprof, "tflops": f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] else 0.0,
                    "gbs": f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] else 0.0,
-                   "traffic_ratio": (f["counter"] / f["counter_alg"]) if f["counter_alg"] else None}
+                   "traffic_ratio": (f["counter"] / f["counter_alg"]) if f["counter_alg"] else None,
+                   "mfma_busy": (f["busy"] / f["busy_ms"]) if f["busy_ms"] else None}
             for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]) if f["flops"] > 0}
         # the HBM-bound layers (C_in = 1 / C_out = 1: arithmetic intensity below the ridge) -- the only fp32 layers
         # where an HBM-roofline fraction is meaningful; worst and best of them
@@ -244,9 +307,14 @@ def main():
               if v["flops"] > 0 and v["ms"] > 0 and v["flops"] / v["bytes"] < RIDGE and v["bytes"] / v["launches"] > 4e6}
         if hb:
             kmin, kmax = min(hb, key=hb.get), max(hb, key=hb.get)
-            roof["hbm_bound_kernels"] = {"worst": {"kernel": kmin, "gbs": hb[kmin], "frac": hb[kmin] / HBM_PEAK_GBS},
-                                         "best": {"kernel": kmax, "gbs": hb[kmax], "frac": hb[kmax] / HBM_PEAK_GBS},
-                                         "all": {k: round(g, 1) for k, g in sorted(hb.items(), key=lambda kv: kv[1])}}
+            # fractions of the 8.0 TB/s spec AND of the guide's measured copy rate (6.29 TB/s: what a pure stream reaches)
+            roof["hbm_bound_kernels"] = {"worst": {"kernel": kmin, "gbs": hb[kmin], "frac": hb[kmin] / HBM_PEAK_GBS,
+                                                   "frac_of_measured_copy": hb[kmin] / HBM_COPY_GBS},
+                                         "best": {"kernel": kmax, "gbs": hb[kmax], "frac": hb[kmax] / HBM_PEAK_GBS,
+                                                  "frac_of_measured_copy": hb[kmax] / HBM_COPY_GBS},
+                                         "all": {k: round(g, 1) for k, g in sorted(hb.items(), key=lambda kv: kv[1])},
+                                         "traffic_ratio": {k: round(traffic[k]["hbm_bytes_per_launch"] * agg[k]["launches"] / agg[k]["bytes"], 3)
+                                                           for k in hb if k in traffic}}
         if args.kernel_table:
             for k, v in sorted(alone.items(), key=lambda kv: -kv[1]["ms"]):
                 s_ = v["ms"] * 1e-3
@@ -276,7 +344,9 @@ def main():
         out = {
             "metric": "CycleGAN train steps/sec on 132^3 x1 uint8 volumes (per-GPU batch of 1 volume; aggregate over GPUs)",
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "sustained_ms_per_step": sustained, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "sustained_ms_per_step": sustained,
+            "sustained_steps": args.sustain if sustained is not None else 0,
+            "sustained_value": (world * 1e3 / sustained) if sustained else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"3D {n}^3 single-channel synthetic volumes, batch={B} per GPU, fp32, "
                                     f"EM2EM.train_step (BASELINE.json configs[1])") if args.dtype == "f32" else

@@ -103,8 +103,9 @@ typedef struct tem_epilogue {
 #define TEM_W_TAP_CI_CO  0
 #define TEM_W_FLIP_CO_CI 1
 /* TEM_W_WINOGRAD: `w` is the layer's kernel in the Winograd F(2x2, 3x3) domain of the (y, x) axes as tem_winograd_weights wrote it
- * (k 3, s 1, C_in and C_out in {8, 16} only; the call returns TEM_EUNSUPPORTED otherwise -- ask
- * tem_conv_is_tiled first).  Same operator and epilogue; the result differs from the direct form by fp32 rounding. */
+ * (k 3, s 1, operator channel pairs C_in -> C_out in {8->8, 8->16, 16->8, 16->16, 16->32, 32->16, 32->32}, epilogues LeakyReLU /
+ * LeakyReLU' gate, and for 16->16 and 32->32 gate + keep bits + split output; the call returns TEM_EUNSUPPORTED
+ * otherwise -- ask tem_conv_is_tiled first).  Same operator and epilogue; the result differs from the direct form by fp32 rounding. */
 #define TEM_W_WINOGRAD   2
 
 typedef struct tem_conv_args {

@@ -21,6 +21,10 @@ rm -rf $OUT/pmc_fetch $OUT/pmc_write
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustain 0 --single-stream --no-kernel-profile > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustain 0 --single-stream --no-kernel-profile > /dev/null 2>&1
 python3 $ROOT/profiles/collect_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/hbm_traffic.json > $OUT/traffic.txt
+# matrix-pipe busy cycles per kernel (north_star: "rocprof HBM GB/s and MFMA-busy"): SQ + GRBM counters, own pass
+rm -rf $OUT/pmc_mfma
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustain 0 --single-stream --no-kernel-profile > /dev/null 2>&1
+python3 $ROOT/profiles/collect_mfma.py $OUT/pmc_mfma $OUT/mfma_busy.json > $OUT/mfma_busy.txt
 echo "pmc done"
 # bf16 mixed precision (BASELINE configs[4], single-GPU share): bench line + kernel table + rocprof stats
 python3 $ROOT/bench.py --dtype bf16 --steps 20 --warmup 5 --kernel-table --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/kernel_table_bf16.txt

@@ -29,6 +29,7 @@ def T():
 
 
 def dev(a):
+    assert a.dtype in (np.float32, np.uint8), a.dtype
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
@@ -60,7 +61,7 @@ def test_winograd_forward_step_shapes(H, T, layer, ci0, ci1, co, n, nskip, lo, h
     rng = np.random.default_rng(n + co)
     ci = ci0 + ci1
     x0 = rnd(rng, 1, n, n, n, ci0)
-    w = rnd(rng, 3, 3, 3, ci, co) * (0.6 / np.sqrt(27 * ci))
+    w = rnd(rng, 3, 3, 3, ci, co) * float(0.6 / np.sqrt(27 * ci))
     x0d = dev(x0)
     if ci1:
         skip = rnd(rng, 1, nskip, nskip, nskip, ci1)
@@ -94,7 +95,7 @@ def test_winograd_input_gradient_step_shapes(H, T, layer, ci, co0, co1, n, mask)
     rng = np.random.default_rng(n + ci)
     co = co0 + co1
     g = rnd(rng, 1, n, n, n, ci)
-    w = rnd(rng, 3, 3, 3, co, ci) * (0.6 / np.sqrt(27 * ci))          # the forward layer's kernel (tap, C_in = co, C_out = ci)
+    w = rnd(rng, 3, 3, 3, co, ci) * float(0.6 / np.sqrt(27 * ci))          # the forward layer's kernel (tap, C_in = co, C_out = ci)
     m = n + 2
     raw = T.conv_bwd_data(g, w, (1, m, m, m, co))
     saved = rnd(rng, 1, m, m, m, co0)
@@ -124,7 +125,7 @@ def test_k4s2_input_gradient_step_shapes(H, T, layer, C, n, nadd, off):
     the LeakyReLU' gate on the skip activation and the skip-gradient window added first (the asymmetric 3 / 4 crop of
     generator.py:75-78 for skip1); odd input edges leave the last voxel without a contribution."""
     rng = np.random.default_rng(n)
-    w = rnd(rng, 4, 4, 4, C, C) * (0.6 / np.sqrt(8 * C))
+    w = rnd(rng, 4, 4, 4, C, C) * float(0.6 / np.sqrt(8 * C))
     o = (n - 4) // 2 + 1
     g = rnd(rng, 1, o, o, o, C)
     saved = rnd(rng, 1, n, n, n, C)
@@ -148,7 +149,7 @@ def test_transposed_convolution_step_shapes(H, T, oracle_lib, layer, CI, CO, n):
     ahead by tem_dropout_masks, as the step does; and the layer's input-gradient (conv_s2_k on the padded k4 s2 form)."""
     rng = np.random.default_rng(n)
     x = rnd(rng, 1, n, n, n, CI)
-    w = rnd(rng, 4, 4, 4, CO, CI) * (0.6 / np.sqrt(8 * CI))
+    w = rnd(rng, 4, 4, 4, CO, CI) * float(0.6 / np.sqrt(8 * CI))
     c = T.convT_fwd(x, w)
     shape = c.shape
     keep = oracle_lib.dropout_mask(shape, 42, 5, 3)
@@ -187,10 +188,10 @@ def test_one_channel_layers_step_shapes(H, T, layer, CI, CO, n, pad, flip, gated
     rng = np.random.default_rng(n + CI)
     x = rnd(rng, 1, n, n, n, CI)
     if flip:          # operator CI -> CO = input-gradient of a CO -> CI layer with Keras kernel (tap, CO, CI)
-        w = rnd(rng, 3, 3, 3, CO, CI) * (0.6 / np.sqrt(27 * CI))
+        w = rnd(rng, 3, 3, 3, CO, CI) * float(0.6 / np.sqrt(27 * CI))
         weff = np.ascontiguousarray(w[::-1, ::-1, ::-1].transpose(0, 1, 2, 4, 3))
     else:
-        w = rnd(rng, 3, 3, 3, CI, CO) * (0.6 / np.sqrt(27 * CI))
+        w = rnd(rng, 3, 3, 3, CI, CO) * float(0.6 / np.sqrt(27 * CI))
         weff = w
     xin, p_eff = (x[:, -pad:pad, -pad:pad, -pad:pad, :], 0) if pad < 0 else (x, pad)
     conv = T.conv_fwd(xin, weff, 1, p_eff)

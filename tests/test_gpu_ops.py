@@ -445,3 +445,35 @@ def test_conv_transpose_mfma_shifted_windows(H, oracle_lib, CI, CO):
             if not direct:
                 assert launch.meta["kernel"].startswith("convT_mfma_k"), launch.meta["kernel"]
         assert rel_err(outs[0], ref) < TOL and rel_err(outs[1], ref) < TOL, (n, pad, lo, osz)
+
+
+@pytest.mark.parametrize("is3d", [True, False])
+def test_downsample_upsample_blocks_are_callable(H, oracle_lib, is3d):
+    """models/utils.downsample / upsample return callables used like the reference's Keras sub-models
+    (`down, skip = downsample(...); skip0 = skip(x); down1 = down(x)`, reference generator.py:60-69,90,102): shared first
+    convolution, N(0, 0.02) kernels in Keras layouts, inference mode by default, Dropout with training=True."""
+    from transfer_em_amd.models.utils import downsample, upsample
+    rng = np.random.default_rng(4)
+    n = 14
+    x = rnd(rng, 2, n if is3d else 1, n, n, 8)
+    down, skip = downsample("1", 8, 8, is3d)
+    up = upsample("2", 8, 8, is3d)
+    skip0, down1 = skip(dev(x)), down(dev(x))
+    kd, ku = [k.cpu().numpy() for k in down.trainable_variables], [k.cpu().numpy() for k in up.trainable_variables]
+    assert len(kd) == 2 and skip.trainable_variables[0] is down.trainable_variables[0]           # models/utils.py:85
+    assert kd[0].shape == ((3, 3, 3) if is3d else (1, 3, 3)) + (8, 8) and ku[1].shape[-2:] == (8, 16)
+    assert 0.015 < kd[1].std() < 0.025                                                           # N(0, 0.02)
+    st2 = (2, 2, 2) if is3d else (1, 2, 2)
+    ref_skip = oracle_lib.leaky_relu(oracle_lib.conv_fwd(x, kd[0], 1, 0))
+    ref_down = oracle_lib.leaky_relu(oracle_lib.conv_fwd(ref_skip, kd[1], st2, 0))
+    assert rel_err(skip0.cpu().numpy(), ref_skip) < TOL and rel_err(down1.cpu().numpy(), ref_down) < TOL
+    y = up(down1)                                                   # inference: Dropout off
+    b = oracle_lib.leaky_relu(oracle_lib.conv_fwd(ref_down, ku[0], 1, 0))
+    ref_up = oracle_lib.leaky_relu(oracle_lib.convT_fwd(b, ku[1], st2, (1, 1, 1) if is3d else (0, 1, 1)))
+    assert y.shape == ref_up.shape and rel_err(y.cpu().numpy(), ref_up) < TOL
+    yt = up(down1, training=True).cpu().numpy()                     # training: half the units dropped, survivors x2
+    zero = (yt == 0)
+    assert 0.4 < zero.mean() < 0.6
+    keep = ~zero
+    pre = oracle_lib.convT_fwd(b, ku[1], st2, (1, 1, 1) if is3d else (0, 1, 1))
+    assert rel_err(yt[keep], oracle_lib.leaky_relu(2 * pre)[keep]) < TOL

@@ -61,3 +61,26 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(d, f)).read()
                 assert "oracle" not in text.replace("oracle/", "").lower() or "import oracle" not in text, f
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+
+
+def test_dry_run_names_the_kernel_the_launch_runs():
+    """tem_conv_is_tiled answers after every geometry check of the tiled kernel: the 8 -> 8 k4 s2 layer at
+    128^3 -> 63^3 is conv_s2_k, the same layer of a dimsize-260 model (256^3 -> 127^3: 1084 tiles per plane, beyond the
+    kernel's magic-division range) is reported -- and launched -- as the generic kernel."""
+    import ctypes as C
+    from transfer_em_amd import _lib
+    lib = _lib.load()
+
+    def args(n, o):
+        a = _lib.tem_conv_args()
+        for v, e in ((a.in0, n), (a.out0, o)):
+            v.ptr, v.N, v.D, v.H, v.W, v.C = 0x10000000, 1, e, e, e, 8
+            v.sW, v.sH, v.sD, v.sN = 8, e * 8, e * e * 8, e * e * e * 8
+        a.w, a.w_layout = 0x20000000, 0
+        a.kd = a.kh = a.kw = 4
+        a.sd = a.sh = a.sw = 2
+        a.ep.slope = 0.3
+        return a
+    name = C.create_string_buffer(96)
+    assert lib.tem_conv_is_tiled(C.byref(args(128, 63)), 0, name, 96) == 1 and name.value.startswith(b"conv_s2_k<8")
+    assert lib.tem_conv_is_tiled(C.byref(args(256, 127)), 0, name, 96) == 0 and not name.value.startswith(b"conv_s2_k")

@@ -167,3 +167,22 @@ def test_paramset_winograd_tables():
     assert H.wino_u_floats(8, 8) == 8192 and H.wino_u_floats(32, 32) == 4 * 2 * H.WINO_U_FLOATS
     P2 = ParamSet(generator_param_shapes(False, 8), "cpu", seed=0)          # 2-D networks: no Winograd layer
     assert P2._utable is None and P2.winograd_launch() is None
+
+
+def test_blocks_are_specs_and_callables():
+    """models/utils.downsample / upsample (reference models/utils.py:41-137): the returned objects are what the
+    planners iterate (ConvSpec lists) AND what reference-style user code calls; without a GPU the call fails loudly."""
+    import torch
+    from transfer_em_amd import _lib
+    from transfer_em_amd.models.utils import Block, downsample, upsample
+    down, skip = downsample("1", 8, 16, True)
+    up = upsample("2", 16, 16, True)
+    assert isinstance(down, Block) and callable(down) and callable(skip) and callable(up)
+    assert [s.kernel for s in down] == [3, 4] and [s.stride for s in down] == [1, 2] and skip.spec == down.spec[:1]
+    assert (down[0].in_ch, down[0].out_ch, down[1].out_ch) == (8, 16, 16)
+    assert [s.kind for s in up] == ["conv", "conv_transpose"] and (up[0].out_ch, up[1].out_ch) == (32, 16)
+    with pytest.raises(RuntimeError, match="apply_dropout=False"):
+        upsample("1", 8, 8, True, apply_dropout=False)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.TemError, match="no CPU fallback"):
+            down(torch.zeros(1, 8, 8, 8, 8))

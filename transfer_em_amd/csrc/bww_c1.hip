@@ -221,7 +221,10 @@ static int run(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out, 
   const int nblocks = cols * zsegs;
   const size_t lds = 8 * 256 * 16 + (size_t)(zper + 2) * (PY + 2) * 18 * 4;       // G ring + X patch (>= the 4 x 27 x CO reduction buffer)
   if (lds > 96 * 1024) return TEM_EUNSUPPORTED;
-  p.gspan = (int)std::min<int64_t>((int64_t)g.sN * 4, (int64_t)0x7fffffff);
+  // bytes one sample of g spans, from the view itself (a batch-1 view may carry any sample stride, 0 included)
+  const int64_t gspan = ((int64_t)(g.D - 1) * g.sD + (int64_t)(g.H - 1) * g.sH + (int64_t)(g.W - 1) * g.sW + g.C) * 4;
+  if (gspan > (int64_t)0x7fffffff) return TEM_EUNSUPPORTED;
+  p.gspan = (int)gspan;
   if (nslab_out) *nslab_out = nblocks;
   if (name) snprintf(name, name_len, "bww_c1_k<%d>", CO);
   if (dry) return TEM_OK;

@@ -410,7 +410,7 @@ bool plan(Dev &p, int max_slabs, size_t &lds_bytes, int &nblocks) {
   p.nych = (p.OH + p.R - 1) / p.R;
   int cols = p.N * p.nych;
   static int target = -1;
-  if (target < 0) { const char *v = getenv("TEM_BWW_BLOCKS"); target = v ? atoi(v) : TARGET_BLOCKS; }
+  if (target < 0) target = tem_env_int("TEM_BWW_BLOCKS", TARGET_BLOCKS);
   int want = max_slabs < target ? max_slabs : target;
   int zsegs = want / cols;
   if (zsegs < 1) zsegs = 1;
@@ -482,7 +482,7 @@ int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
   if (!aligned(i0) || (a->in1.ptr && !aligned(a->in1)) || !aligned(g)) return TEM_EUNSUPPORTED;
   //        CI  CO  K  S  waves  X-chunks  G-chunks     (tiles per wave = ceil(K^3*CI/16 * ceil(CO/16) / waves))
   static int xsh = -1;
-  if (xsh < 0) { const char *v = getenv("TEM_BWW_XSH"); xsh = v ? atoi(v) : 1; }
+  if (xsh < 0) xsh = tem_env_int("TEM_BWW_XSH", 1);
   BWW_CASE_XSH(8, 8, 3, 1, 8, 4, 3)  // g.d1a: 9 tiles in the x-shift form
   BWW_CASE_XSH(8, 8, 4, 2, 8, 6, 2)  // g.d1b / d.d1b: 16 tiles
   BWW_CASE(1, 8, 3, 1, 8, 3, 4)      // g.c0 / d.d1a: 2 tiles x 4 row shares, HBM-bound on the gradient stream

@@ -403,7 +403,7 @@ static int run(Dev p, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   // (32 input channels: a slab is 110-260 KB; 64 ranges x kz = one workgroup per CU already, and half the slab traffic of 128)
   int R = (lds_bytes <= 80 * 1024 && CI != 32) ? 128 : 64;
   static int rr = -1;
-  if (rr < 0) { const char *v = getenv("TEM_BWW_S2_R"); rr = v ? atoi(v) : 0; }
+  if (rr < 0) rr = tem_env_int("TEM_BWW_S2_R", 0);
   if (rr > 0) R = rr;
   while (R > 1 && p.rows / R < (CI == 32 ? 2 : 8)) R >>= 1;     // (32 input channels: every wave walks all rows of the range)
   if (R > max_slabs) R = max_slabs;
@@ -427,9 +427,9 @@ static int run_tb(Dev p, int max_slabs, hipStream_t st, bool dry, int *nslab_out
   const size_t lds_bytes = (size_t)4 * 16 * 64 * 16;            // 64 KB: two workgroups per CU
   int R = 512;
   static int rr = -1;
-  if (rr < 0) { const char *v = getenv("TEM_BWW_S2_TBR"); rr = v ? atoi(v) : 0; }
+  if (rr < 0) rr = tem_env_int("TEM_BWW_S2_TBR", 0);
   static int nb = -1;
-  if (nb < 0) { const char *v = getenv("TEM_BWW_S2_TBN"); nb = v ? atoi(v) : 8; }
+  if (nb < 0) nb = tem_env_int("TEM_BWW_S2_TBN", 8);
   if (rr > 0) R = rr;
   else while (R > 1 && p.rows / R < 8) R >>= 1;                      // at least two rows per wave
   if (R > max_slabs) R = max_slabs;
@@ -459,7 +459,7 @@ static int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_
   if (!k4s2 && !k3s1) return TEM_EUNSUPPORTED;
   if (a->pd != a->ph || a->ph != a->pw) return TEM_EUNSUPPORTED;
   static int enabled = -1;
-  if (enabled < 0) { const char *v = getenv("TEM_BWW_S2"); enabled = v ? atoi(v) : 1; }
+  if (enabled < 0) enabled = tem_env_int("TEM_BWW_S2", 1);
   if (!enabled) return TEM_EUNSUPPORTED;
   if (g.N != i0.N) return TEM_ESHAPE;
   const int64_t ispan = span_of(i0), gspan = span_of(g);
@@ -481,14 +481,14 @@ static int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_
   p.slabs = a->slabs; p.slab_stride = stride;
   if (k4s2 && CI == 8 && CO == 8) {                 // g.d1b, d.d1b: two-block rows (with plain rows half of every m-tile is zeros: 73 us)
     static int tb = -1;
-    if (tb < 0) { const char *v = getenv("TEM_BWW_S2_TB"); tb = v ? atoi(v) : 1; }
+    if (tb < 0) tb = tem_env_int("TEM_BWW_S2_TB", 1);
     if (!tb) return TEM_EUNSUPPORTED;
     return run_tb(p, a->nslab, st, dry, nslab_out);
   }
   if (k3s1) {
     // the 3x3x3 layers the Winograd-domain kernel leaves alone (hip_ops.WINO_MIN_VOXELS): g.u2a, d.d3a
     static int k3 = -1;
-    if (k3 < 0) { const char *v = getenv("TEM_BWW_S2_K3"); k3 = v ? atoi(v) : 1; }
+    if (k3 < 0) k3 = tem_env_int("TEM_BWW_S2_K3", 1);
     if (!k3 || (int64_t)g.D * g.H * g.W > 40000) return TEM_EUNSUPPORTED;
     if (CI == 16 && CO == 32) return run<16, 32, 3, 1>(p, a->nslab, st, dry, nslab_out);
     if (CI == 32 && CO == 32) return run<32, 32, 3, 1>(p, a->nslab, st, dry, nslab_out);

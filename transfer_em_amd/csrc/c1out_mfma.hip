@@ -197,7 +197,7 @@ static int run(Dev p, int N, hipStream_t st, bool dry) {
   int zper = (p.OD + zsegs - 1) / zsegs;
   if (zper < 8) zper = p.OD < 8 ? p.OD : 8;
   static int zp = -1;
-  if (zp < 0) { const char *v = getenv("TEM_C1OUT_ZPER"); zp = v ? atoi(v) : 0; }
+  if (zp < 0) zp = tem_env_int("TEM_C1OUT_ZPER", 0);
   if (zp > 0) zper = zp < p.OD ? zp : p.OD;
   p.zper = zper;
   p.zsegs = (p.OD + zper - 1) / zper;
@@ -222,7 +222,7 @@ static int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   if (a->ep.dropout || a->ep.add.ptr) return TEM_EUNSUPPORTED;
   if (i0.C != 16) return TEM_EUNSUPPORTED;          // (8 -> 1, the input-gradients of the first convolutions: measured slower than c1_stencil_k, 51 vs 38 us)
   static int enabled = -1;
-  if (enabled < 0) { const char *v = getenv("TEM_C1OUT_MFMA"); enabled = v ? atoi(v) : 1; }
+  if (enabled < 0) enabled = tem_env_int("TEM_C1OUT_MFMA", 1);
   if (!enabled) return TEM_EUNSUPPORTED;
   if (o0.N != i0.N) return TEM_ESHAPE;
   if (!fits32(i0) || !fits32(o0)) return TEM_EUNSUPPORTED;

@@ -302,7 +302,7 @@ int run(Dev p, int N, const u16 *w, hipStream_t st, bool dry) {
     return TEM_OK;
   }
   static int dbg = -1;
-  if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
+  if (dbg < 0) dbg = tem_env_int("TEM_DEBUG_FLAGS", 0);
   const size_t lds_bytes = (((size_t)2 * p.rows * p.cols * CIP + 7) & ~(size_t)7) * 2 + 4 * 16 * 20 * 4;
   const int nblocks = N * p.nband * p.nQz * (4 / NCLS);
   if (dbg & 8)

@@ -318,7 +318,7 @@ int run(Dev p, int N, const float *w, hipStream_t st, bool dry, int epm) {
     return TEM_OK;
   }
   static int dbg = -1;
-  if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
+  if (dbg < 0) dbg = tem_env_int("TEM_DEBUG_FLAGS", 0);
   const size_t lds_bytes = ((((size_t)2 * p.rows * p.cols * CIP + 3) & ~(size_t)3) + 4 * 16 * 20) * 4;
   const int nblocks = N * p.nband * p.nQz * (4 / NCLS);
   if (dbg & 8)
@@ -339,7 +339,7 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   if (o0.N != i0.N) return TEM_ESHAPE;
   if (!fits32(i0) || !fits32(o0)) return TEM_EUNSUPPORTED;
   static int enabled = -1;
-  if (enabled < 0) { const char *v = getenv("TEM_CONVT_MFMA"); enabled = v ? atoi(v) : 1; }
+  if (enabled < 0) enabled = tem_env_int("TEM_CONVT_MFMA", 1);
   if (!enabled) return TEM_EUNSUPPORTED;
   auto aligned = [](const tem_view &v) {
     return ((uintptr_t)v.ptr & 15) == 0 && v.sW % 4 == 0 && v.sH % 4 == 0 && v.sD % 4 == 0 && v.sN % 4 == 0;
@@ -391,7 +391,7 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   }
   const int CI = i0.C, CO = o0.C, N = i0.N;
   static int epm_on = -1;
-  if (epm_on < 0) { const char *v = getenv("TEM_CONVT_EPM"); epm_on = v ? atoi(v) : 1; }
+  if (epm_on < 0) epm_on = tem_env_int("TEM_CONVT_EPM", 1);
   int epm = 0;
   if (epm_on) {
     if (q.dropout && q.keep_mode == 2 && !q.gate && !q.add) epm = 1;

@@ -389,7 +389,7 @@ int run(Dev p, int N, hipStream_t st, bool dry) {
     return TEM_OK;
   }
   static int dbg = -1;
-  if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
+  if (dbg < 0) dbg = tem_env_int("TEM_DEBUG_FLAGS", 0);
   const int nblocks = N * p.nby * p.nbx * p.OD;
   if (dbg & 8)
     fprintf(stderr, "conv_bf16<%d,%d,%d,%d> O=%dx%dx%d P=%d: TX=%d TY=%d patch=%dx%d blocks=%d lds=%zu\n", CI, CO, K, S, p.OD,

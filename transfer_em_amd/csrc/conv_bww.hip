@@ -229,13 +229,21 @@ extern "C" int tem_conv_bwd_weight(const tem_bww_args *a, tem_stream_t stream) {
     int n = 0;
     {
       // (the C_in = 1 kernel sizes its z runs by the slab budget: ask with the caller's own count as the budget)
-      if (tem_bww_c1_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab)
-        return tem_bww_c1_try(a, (hipStream_t)stream, false, nullptr);
+      if (tem_bww_c1_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab) {
+        const int rc = tem_bww_c1_try(a, (hipStream_t)stream, false, nullptr);
+        if (rc != TEM_EUNSUPPORTED) return rc;
+      }
     }
-    if (tem_bww_s2_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab)
-      return tem_bww_s2_try(a, (hipStream_t)stream, false, nullptr);
-    if (tem_bww_lds_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab)
-      return tem_bww_lds_try(a, (hipStream_t)stream, false, nullptr);
+    // a tiled kernel that declines at launch time (a check only the launch can make, e.g. the slab alignment) hands the
+    // call on to the next kernel instead of failing it
+    if (tem_bww_s2_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab) {
+      const int rc = tem_bww_s2_try(a, (hipStream_t)stream, false, nullptr);
+      if (rc != TEM_EUNSUPPORTED) return rc;
+    }
+    if (tem_bww_lds_try(a, nullptr, true, &n) == TEM_OK && n == a->nslab) {
+      const int rc = tem_bww_lds_try(a, (hipStream_t)stream, false, nullptr);
+      if (rc != TEM_EUNSUPPORTED) return rc;
+    }
   }
   BwwDev p{};
   const tem_view &i0 = a->in0, &g = a->dout;

@@ -423,7 +423,7 @@ static int conv_direct_impl(const tem_conv_args *a, hipStream_t st, char *name, 
     // C_out is 1 and for the forward 8->8 layer; the [co][ci]-layout 8/16-channel cases and the strided
     // layer stay on conv_direct_k (TEM_ROWS=0 disables it for A/B runs)
     static int rows = -1;
-    if (rows < 0) { const char *v = getenv("TEM_ROWS"); rows = v ? atoi(v) : 1; }
+    if (rows < 0) rows = tem_env_int("TEM_ROWS", 1);
     if (rows && p.OH >= 16) {
       ROWS_CASE(8, 8, false, 3, 1, 4)
       ROWS_CASE(1, 8, false, 3, 1, 4) ROWS_CASE(8, 1, true, 3, 1, 4)
@@ -431,7 +431,7 @@ static int conv_direct_impl(const tem_conv_args *a, hipStream_t st, char *name, 
     }
     // TEM_ROWS2 (bit mask, perf triage): row-blocked form for the k4 s2 layers (bit 0), 8->16 / 16->8 k3 (bit 1)
     static int rows2 = -1;
-    if (rows2 < 0) { const char *v = getenv("TEM_ROWS2"); rows2 = v ? atoi(v) : 0; }
+    if (rows2 < 0) rows2 = tem_env_int("TEM_ROWS2", 0);
     if (p.OH >= 16 && a->kw == a->kh && a->kd == a->kh) {
       if (rows2 & 1) { ROWS_CASE(8, 8, false, 4, 2, 2) ROWS_CASE(8, 16, false, 4, 2, 2) }
       if (rows2 & 4) { ROWS_CASE(8, 8, false, 4, 2, 4) ROWS_CASE(8, 16, false, 4, 2, 4) }

@@ -304,22 +304,24 @@ static thread_local int g_name_len = 0;
 template <int CI, int NT, int T, bool TB = false>
 static int run(Dev p, hipStream_t st, bool dry) {
   constexpr int NWAVE = CI / 2, VPT = TB ? 15 : 16;
-  if (dry) {
-    if (g_name) snprintf(g_name, g_name_len, "conv_s2_k<%d, %d, %d, %s>", CI, NT, T, TB ? "true" : "false");
-    return TEM_OK;
-  }
+  // every geometry check comes BEFORE the dry-run answer: tem_conv_is_tiled / Launch.meta must name the kernel the launch
+  // really runs (a 260^3 model's g.d1b has tiles_pp = 1084 and falls through to the generic kernel)
   p.RL = TB ? p.OW + 1 : p.OW;
   p.plane_vox = p.OH * p.RL;
   p.tiles_pp = (p.plane_vox + VPT - 1) / VPT;
   const int64_t total = (int64_t)p.oN_count * p.OD * p.tiles_pp;
   if (total > (1 << 22) || p.tiles_pp > 1024 || p.OW > 1024) return TEM_EUNSUPPORTED;    // range of the magic divisions
+  if (dry) {
+    if (g_name) snprintf(g_name, g_name_len, "conv_s2_k<%d, %d, %d, %s>", CI, NT, T, TB ? "true" : "false");
+    return TEM_OK;
+  }
   p.total = (int)total;
   p.magicOW = magic_for(p.RL); p.magicTpp = magic_for(p.tiles_pp); p.magicOD = magic_for(p.OD);
   p.iters = (p.total + T - 1) / T;
   // as many workgroups as are resident at once (each keeps its B fragment for its whole contiguous range of tiles: the
   // ~3 us prologue -- B loads, first A loads -- is paid once per CU slot; more, shorter workgroups measured 15-25 % slower)
   static int mult = -1;
-  if (mult < 0) { const char *v = getenv("TEM_S2_WGS"); mult = v ? atoi(v) : 1; }
+  if (mult < 0) mult = tem_env_int("TEM_S2_WGS", 1);
   const int ny = (p.CO + 16 * NT - 1) / (16 * NT);
   const int resident = 256 * (CI == 8 ? 2 : 1) * mult / ny;
   const int nblocks = p.iters < resident ? p.iters : resident;
@@ -345,7 +347,7 @@ static int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   if (a->kd != 4 || a->kh != 4 || a->kw != 4 || a->sd != 2 || a->sh != 2 || a->sw != 2) return TEM_EUNSUPPORTED;
   if (a->pd != a->ph || a->ph != a->pw) return TEM_EUNSUPPORTED;
   static int enabled = -1;
-  if (enabled < 0) { const char *v = getenv("TEM_CONV_S2"); enabled = v ? atoi(v) : 1; }
+  if (enabled < 0) enabled = tem_env_int("TEM_CONV_S2", 1);
   if (!enabled) return TEM_EUNSUPPORTED;
   if (o0.N != i0.N) return TEM_ESHAPE;
   if (!fits32(i0) || !fits32(o0)) return TEM_EUNSUPPORTED;
@@ -380,11 +382,11 @@ static int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   p.out = o0.ptr; p.oN = (int)o0.sN; p.oD = (int)o0.sD; p.oH = (int)o0.sH; p.oW = (int)o0.sW;
   p.OD = o0.D; p.OH = o0.H; p.OW = o0.W; p.CO = o0.C; p.oN_count = o0.N;
   p.P = a->pd;
-  { static int dbg = -1; if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; } p.dbg = dbg; }
+  { static int dbg = -1; if (dbg < 0) dbg = tem_env_int("TEM_DEBUG_FLAGS", 0); p.dbg = dbg; }
   p.plane_vox = o0.H * o0.W;
   const int CI = i0.C, CO = o0.C;
   static int tb = -1;
-  if (tb < 0) { const char *v = getenv("TEM_S2_TB"); tb = v ? atoi(v) : 1; }
+  if (tb < 0) tb = tem_env_int("TEM_S2_TB", 1);
   if (tb && CI == 8 && CO == 8) return run<8, 1, 4, true>(p, st, dry);           // g.d1b, d.d1b: two-block form
   if (CI == 8 && (CO == 8 || CO == 16)) return run<8, 1, 2>(p, st, dry);     // 8 -> 8 without the two-block form (fallback); input-gradient of g.u1b
   if (CI == 16 && CO == 16) return run<16, 1, 2>(p, st, dry);                // g.d2b

@@ -415,7 +415,7 @@ int run(Dev p, int N, hipStream_t st, bool dry) {
     return TEM_OK;
   }
   static int dbg = -1;
-  if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
+  if (dbg < 0) dbg = tem_env_int("TEM_DEBUG_FLAGS", 0);
   p.dbg = dbg;
   if (dbg & 8)
     fprintf(stderr, "c1_stencil<%d,%d> OW=%d OH=%d OD=%d: TX=%d TY=%d zper=%d zsegs=%d blocks=%d\n", CI, CO, p.OW, p.OH,
@@ -468,7 +468,7 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   if (o0.N != i0.N) return TEM_ESHAPE;
   if (!fits32(i0) || !fits32(o0)) return TEM_EUNSUPPORTED;
   static int enabled = -1;
-  if (enabled < 0) { const char *v = getenv("TEM_STENCIL_C1"); enabled = v ? atoi(v) : 1; }
+  if (enabled < 0) enabled = tem_env_int("TEM_STENCIL_C1", 1);
   if (!enabled) return TEM_EUNSUPPORTED;
   const int CI = i0.C, CO = o0.C;
   auto aligned = [](const tem_view &v) {
@@ -491,11 +491,11 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   }
   const bool flip = a->w_layout == TEM_W_FLIP_CO_CI;
   const int N = i0.N;
-  { static int dbg = -1; if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; } p.dbg = dbg; }
+  { static int dbg = -1; if (dbg < 0) dbg = tem_env_int("TEM_DEBUG_FLAGS", 0); p.dbg = dbg; }
 #define C1_CASE(ci, co, pf) \
   if (CI == ci && CO == co) return flip ? run<ci, co, true, pf>(p, N, st, dry) : run<ci, co, false, pf>(p, N, st, dry);
   static int use_mfma = -1;
-  if (use_mfma < 0) { const char *v = getenv("TEM_C1_MFMA"); use_mfma = v ? atoi(v) : 1; }
+  if (use_mfma < 0) use_mfma = tem_env_int("TEM_C1_MFMA", 1);
   if (use_mfma && CI == 1 && CO == 8)      // g.c0, d.d1a forward
     return flip ? run_mfma<8, true>(p, N, st, dry) : run_mfma<8, false>(p, N, st, dry);
   if (use_mfma && CI == 1 && CO == 16)     // input-gradient of g.f2 (gated by f1)

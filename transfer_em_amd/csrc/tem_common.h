@@ -4,6 +4,19 @@
 #include <stdint.h>
 #include "../../include/tem_hip.h"
 
+// Tuning / ablation knobs (TEM_DEBUG_FLAGS, stamp buffers, kernel on/off switches) are read from the environment only in
+// builds with -DTEM_DEBUG_KNOBS (the microbenchmarks under tests/tools: TEM_BUILD_FLAGS=-DTEM_DEBUG_KNOBS python -m
+// transfer_em_amd.build --force).  The shipped library ignores the environment: no result-changing debug bit and no
+// device address can reach a kernel from outside the C ABI.
+#ifdef TEM_DEBUG_KNOBS
+#include <stdlib.h>
+static inline int tem_env_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+static inline unsigned long long tem_env_hex(const char *name) { const char *v = getenv(name); return v ? strtoull(v, nullptr, 16) : 0ull; }
+#else
+static inline int tem_env_int(const char *, int dflt) { return dflt; }
+static inline unsigned long long tem_env_hex(const char *) { return 0ull; }
+#endif
+
 #define TEM_CHECK_LAUNCH()                         \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \

@@ -543,10 +543,10 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   p.P = a->pd;
   {
     static int dbg = -1;
-    if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
+    if (dbg < 0) dbg = tem_env_int("TEM_DEBUG_FLAGS", 0);
     p.dbg = dbg;
     static unsigned long long stamp_ptr = ~0ull;
-    if (stamp_ptr == ~0ull) { const char *v = getenv("TEM_WINO_STAMP_BUF"); stamp_ptr = v ? strtoull(v, nullptr, 16) : 0; }
+    if (stamp_ptr == ~0ull) stamp_ptr = tem_env_hex("TEM_WINO_STAMP_BUF");
     p.stamps = (unsigned long long *)stamp_ptr;
   }
   const tem_epilogue &e = a->ep;

@@ -454,7 +454,7 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
   p.slabs = a->slabs; p.slab_stride = a->slab_stride ? a->slab_stride : (int64_t)27 * CI * dy.C;
   {
     static int dbg = -1;
-    if (dbg < 0) { const char *v = getenv("TEM_DEBUG_FLAGS"); dbg = v ? atoi(v) : 0; }
+    if (dbg < 0) dbg = tem_env_int("TEM_DEBUG_FLAGS", 0);
     p.dbg = dbg;
   }
   if (p.dbg & 8)

@@ -37,9 +37,13 @@ def unstandardize_population(tensor, meanstd):
     return tensor * float(std) + float(mean)
 
 
-def get_meanstd(dataset):
+def get_meanstd(dataset, replicas=False):
     """Global mean and standard deviation: mean of per-tensor means, sqrt of the mean of
-    per-tensor variances (datasets.py:173-190)."""
+    per-tensor variances (datasets.py:173-190).
+
+    replicas=True under an initialised torch.distributed process group: the per-tensor sums and the count are summed
+    over the ranks first, so every data-parallel replica standardizes with the SAME population statistics (those of
+    the union of the ranks' samples) -- what a single-process run over the whole stream would have used."""
     mean = 0.0
     var = 0.0
     count = 0
@@ -48,6 +52,15 @@ def get_meanstd(dataset):
         t = np.asarray(tensor, np.float32)
         mean += float(t.mean(dtype=np.float32))
         var += float(t.var(dtype=np.float32))
+    if replicas:
+        import torch
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            acc = torch.tensor([mean, var, float(count)], dtype=torch.float64)
+            if dist.get_backend() == "nccl":          # RCCL reduces device tensors only
+                acc = acc.cuda()
+            dist.all_reduce(acc)
+            mean, var, count = (float(v) for v in acc.cpu())
     mean /= count
     var /= count
     return np.float32(mean), np.float32(np.sqrt(var))
@@ -216,7 +229,17 @@ def create_dataset_from_tensors(tensors, custom_map=None, batch_size=BATCH_SIZE,
     return Dataset(samples, batch_size, enable_augmentation, randomize, seed, device, rank, world_size), meanstd
 
 
-MEANSTD_SAMPLES = 64   # samples of the stream used for the population statistics when `meanstd` is not given
+MEANSTD_SAMPLES = 64            # least number of samples of the stream used for the population statistics
+MEANSTD_VOXELS = 64 * 132 ** 3  # ... and the voxel budget that extends it for small samples (2-D tiles: the whole epoch)
+
+
+def meanstd_samples(sample_voxels, epoch_size):
+    """Samples of the statistics pass: the reference walks a whole take(epoch_size) pass (datasets.py:108-111); here the
+    pass is bounded by a voxel budget -- 64 volumes of 132^3, i.e. every sample of an epoch of 2-D tiles (4096 x 132^2 is
+    half of it) but only the first 64 of a stream of 10^6-voxel volumes, where the mean of per-sample means / variances
+    has long converged."""
+    by_budget = -(-MEANSTD_VOXELS // max(int(sample_voxels), 1))
+    return int(min(int(epoch_size), max(MEANSTD_SAMPLES, by_budget)))
 
 
 def create_dataset_from_generator(dataset, shape=None, custom_map=None, batch_size=BATCH_SIZE, epoch_size=EPOCH_SIZE,
@@ -227,16 +250,21 @@ def create_dataset_from_generator(dataset, shape=None, custom_map=None, batch_si
 
     meanstd=None with global_adjust: the reference walks one whole `take(epoch_size)` pass of the stream
     eagerly (datasets.py:108-111) and then re-draws for training; here the statistics come from one BOUNDED
-    pass -- the first min(epoch_size, MEANSTD_SAMPLES) samples, which are then used as the head of epoch 1
-    instead of being thrown away (mean of per-sample means / variances converges with few 10^6-voxel volumes)."""
+    pass (meanstd_samples: the whole epoch for 2-D tiles, the first 64 volumes of a 3-D stream), whose samples are
+    then used as the head of epoch 1 instead of being thrown away.  Under data parallelism (torch.distributed
+    initialised, every rank drawing its own crops) the ranks' statistics are combined before anything is
+    standardized, so all replicas -- and the checkpoint / meta.json rank 0 writes -- share one (mean, std)."""
     source = iter(dataset)
     first = []
     if global_adjust and meanstd is None:
+        limit = None
         for t in source:
             first.append(_prepare_one(t, custom_map, padding))
-            if len(first) >= min(int(epoch_size), MEANSTD_SAMPLES):
+            if limit is None:
+                limit = meanstd_samples(first[0].size, epoch_size)
+            if len(first) >= limit:
                 break
-        meanstd = get_meanstd(first)
+        meanstd = get_meanstd(first, replicas=True)
     if global_adjust:
         ms = meanstd
         prepare = lambda t: standardize_population(_prepare_one(t, custom_map, padding), ms)

@@ -85,11 +85,13 @@ def _p3(p, is3d):
 
 def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=None, layout=TEM_W_TAP_CI_CO,
                 transposed=False, slope=1.0, bias=None, gate=None, gate_slope=LEAKY, add=None, add_off=0,
-                dropout=None, drop_frame=None, keep_mask=None, direct=False, wino=None):
+                dropout=None, drop_frame=None, keep_mask=None, direct=False, wino=None, bwd_data=False):
     """Build a tem_conv / tem_conv_transpose launch.  `w` and `bias` are 1-D float32 tensors
     (slices of a network's flat parameter vector); dropout = (seed, site, step_dev_tensor).
     wino: the layer's Winograd-domain kernel copy (ParamSet.u); used instead of `w` when the library runs this
-    geometry and epilogue in the Winograd form (tem_conv_is_tiled with TEM_W_WINOGRAD), ignored otherwise."""
+    geometry and epilogue in the Winograd form (tem_conv_is_tiled with TEM_W_WINOGRAD), ignored otherwise.
+    bwd_data: the launch is the input-gradient of a stride-1 layer (a pad-(k-1) convolution over the output gradient):
+    only the flop count of Launch.meta depends on it (SURVEY 8(d) prices a pass by the FORWARD layer's output voxels)."""
     lib = _lib.load()
     a = tem_conv_args()
     keep = [in0, w, out0]
@@ -170,7 +172,11 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
     # algorithmic bytes of the fused operator: input, output, kernel, plus the tensors its epilogue has to read (the saved
     # activation behind a LeakyReLU-gradient gate, a skip-gradient window)
     ep_bytes = (esz * co0 * vout if gate is not None else 0.0) + (esz * add.numel() if add is not None else 0.0)
-    meta = dict(flops=2.0 * ntap * ci * co * (vin if transposed else vout),
+    # flops of a pass = 2 * taps * C_in * C_out * (output voxels of the FORWARD layer).  For the input-
+    # gradient of a stride-1 layer those are this launch's INPUT voxels (the gradient tensor), not the padded output
+    # (100^3 instead of 98^3: +6 %); `flops_operator` keeps the operator's own count for reference.
+    meta = dict(flops=2.0 * ntap * ci * co * (vin if (transposed or bwd_data) else vout),
+                flops_operator=2.0 * ntap * ci * co * (vin if transposed else vout),
                 bytes=esz * (ci * vin + co * vout) + 4.0 * ntap * ci * co + ep_bytes, kernel=kern,
                 shape=f"{ci0}+{ci1}@{tuple(in0.shape[:4])} -> {co0}+{co1}@{tuple(out0.shape[:4])} k{k} s{s} p{p}")
     return Launch(fn, (C.byref(a),), name, keep + [a], meta)

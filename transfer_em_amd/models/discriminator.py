@@ -160,7 +160,7 @@ class DiscBackward:
                                        dst, k, 1, k - 1,
                                        is3d=i3, out1=g_feat if with_prior else None,
                                        layout=H.TEM_W_TAP_CI_CO if use_t else H.TEM_W_FLIP_CO_CI,
-                                       gate=gate, gate_slope=gslope, direct=direct,
+                                       gate=gate, gate_slope=gslope, direct=direct, bwd_data=True,
                                        wino=None if (bf or direct or with_prior) else P.u(name, bwd=True)))
             else:
                 L.append(H.conv_launch("d.bd." + name, g_out, P.wh(name) if bf else P.w(name), dst, k, s, 0, is3d=i3,

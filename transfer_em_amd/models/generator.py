@@ -269,7 +269,7 @@ class GenBackward:
         def cvb(lname, gin, name, gout, pad, **k2):
             wsel = wb(name)
             wn = None if (bf or direct) else P.u(name, bwd=True)
-            return cv(lname, gin, wsel["w"], gout, 3, 1, pad, layout=wsel["layout"], wino=wn, **k2)
+            return cv(lname, gin, wsel["w"], gout, 3, 1, pad, layout=wsel["layout"], wino=wn, bwd_data=True, **k2)
         # every input-gradient of a stride-1 VALID conv is a conv with pad k-1 = 2 over the output gradient
         L.append(bww("f2", A["f1"], dy, 3, 1, pc(0, 1, "f1", "f2")))
         L.append(cvb("g.bd.f2", dy, "f2", G["f1"], pc(2, 1, "f2", "f1"), gate=A["f1"], **kw))
@@ -340,9 +340,22 @@ class UNetGenerator:
         key = tuple(int(v) for v in shape) + (dtype,)
         plan = self._plans.get(key)
         if plan is None:
+            # a plan pins every activation of its batch (27 tiles of 132^3: ~10 GB).  Keep the most recent MAX_PLANS
+            # shapes only, so that a predict_cube during training (sample / check_freq) cannot park tens of GB beside the
+            # train step's buffers for the model's lifetime; clear_plans() releases them all.
+            while len(self._plans) >= self.MAX_PLANS:
+                self._plans.pop(next(iter(self._plans)))
             buf = torch.empty(key[:-1], dtype=dtype, device=self.device)
             plan = self._plans[key] = GenForward(self, buf, pack=True)
+        else:
+            self._plans[key] = self._plans.pop(key)          # most recently used last
         return plan
+
+    MAX_PLANS = 2            # e.g. the full chunk and the remainder chunk of one tiled prediction
+
+    def clear_plans(self):
+        """Release the cached inference plans (their activation buffers go back to the allocator)."""
+        self._plans.clear()
 
     def __call__(self, x, training=False):
         """Inference forward (Keras __call__ without training=True: dropout off, cgan.py:289-293)."""
