@@ -213,8 +213,8 @@ def test_one_channel_layers_step_shapes(H, T, layer, CI, CO, n, pad, flip, gated
 
 
 # (layer, C_in, C_out, k, stride, pad, input edge, expected kernel prefix)
-BWW = [("g.bww.c0", 1, 8, 3, 1, 0, 132, "bww_c1_k<8"), ("d.bww.d1a", 1, 8, 3, 1, 0, 96, "bww_c1_k<8"),
-       ("g.bww.f2", 16, 1, 3, 1, 0, 98, "bww_c1_k<16"), ("g.bww.f1", 16, 16, 3, 1, 0, 100, "wino_bww_k"),
+BWW = [("g.bww.c0", 1, 8, 3, 1, 0, 132, "bww_c1m_k<8"), ("d.bww.d1a", 1, 8, 3, 1, 0, 96, "bww_c1m_k<8"),
+       ("g.bww.f2", 16, 1, 3, 1, 0, 98, "bww_c1m_k<16"), ("g.bww.f1", 16, 16, 3, 1, 0, 100, "wino_bww_k"),
        ("g.bww.d1a", 8, 8, 3, 1, 0, 130, "wino_bww_k"), ("g.bww.mid", 32, 32, 3, 1, 0, 54, "wino_bww_k"),
        ("g.bww.u1a", 32, 16, 3, 1, 0, 52, "wino_bww_k"), ("g.bww.d1b", 8, 8, 4, 2, 0, 128, "bww_s2tb_k"),
        ("g.bww.d2b", 16, 16, 4, 2, 0, 61, "bww_s2_k"), ("d.bww.d2b", 32, 32, 4, 2, 0, 42, "bww_s2_k")]

@@ -1,6 +1,6 @@
 """One data-parallel replica of the product's train step (tests/test_gpu_dp.py; launched by dp_spawner.py).
 
-    dp_rank.py OUTDIR [3d]
+    dp_rank.py OUTDIR [3d] [steps=N]
 
 Ranks share ONE card and exchange gradients over gloo (RCCL needs one GPU per rank; the product code path --
 bucketed all-reduce on the step's streams, grad_scale = 1/world in the Adam kernel, parameter broadcast, per-rank
@@ -19,7 +19,8 @@ import torch.distributed as dist
 
 
 def main():
-    outdir, is3d = sys.argv[1], len(sys.argv) > 2 and sys.argv[2] == "3d"
+    outdir, is3d = sys.argv[1], "3d" in sys.argv[2:]
+    nsteps = next((int(a[6:]) for a in sys.argv[2:] if a.startswith("steps=")), 2)
     dist.init_process_group(os.environ.get("TEM_DIST_BACKEND", "gloo"))
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
@@ -40,7 +41,7 @@ def main():
     shape = (1, n if is3d else 1, n, n, 1)
     x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
     y = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
-    losses = [model.train_step(x, y).cpu().numpy() for _ in range(2)]
+    losses = [model.train_step(x, y).cpu().numpy() for _ in range(nsteps)]
     ck = model.make_checkpoint(1)
     out = {"init": init, "losses": np.stack(losses), "grad_all": model.grad_all.cpu().numpy(),
            "seed": np.int64(model.seed), "ckpt": np.array(ck or ""), "step": model.step_dev.cpu().numpy()}

@@ -207,45 +207,59 @@ __global__ __launch_bounds__(256, CI == 16 ? 3 : 4) void c1_stencil_k(Dev p, con
 }
 
 // ------------------------------------------------------------------------------------------ C_in == 1 on the matrix cores
-// out[v][co] = sum_tap x[v + tap] * w[tap][co] is a [voxels x 27] x [27 x C_out] product.  v_mfma_f32_16x16x4_f32 with
-// M = 16 consecutive voxels of a row and the 27 taps as the K dimension keeps every kernel tap in REGISTERS (the B
-// fragments: one VGPR per k-step, loaded once per wave) -- the VALU form has to stream all 27 x C_out taps through the
-// scalar path for every output voxel.  C_out == 8 would fill half of the 16 columns: the other half takes the NEXT
-// output plane (columns = (plane, co)), K then spans the 4 input planes the plane pair touches (36 = 9 k-steps, 27 of
-// the 36 products per column are real).  C_out == 16: K = 27 padded to 28 (7 k-steps).
-// A workgroup loads its input patch (1 channel: a few KB) into LDS once, every wave gathers its A fragments from it
-// (ds_read_b32, lane -> (voxel, tap)), and the 16x16 result tile is transposed through a private LDS patch so that
-// each lane stores 16 contiguous bytes (1 KB per wave instruction), with bias / LeakyReLU / gate fused.
+// out[v][co] = sum_tap x[v + tap] * w[tap][co] is a [27 x C_out]^T x [27 x voxels] product.  v_mfma_f32_16x16x4_f32 with the
+// 27 taps as the K dimension keeps every kernel tap in REGISTERS (one VGPR per k-step, loaded once per wave) -- the VALU form
+// has to stream all 27 x C_out taps through the scalar path for every output voxel.  The kernel is the M side (rows =
+// output channels), 16 consecutive voxels of a row the N side: the C/D map (column = lane & 15, rows 4 (lane >> 4) + r) then
+// leaves a lane with FOUR CONSECUTIVE CHANNELS OF ONE VOXEL -- a 16-byte store straight from the accumulator, no transpose
+// (round 2 had the voxels as rows and sent every tile through an LDS patch: 5 LDS operations and a wait per tile).
+// C_out == 8 would fill half of the 16 rows: the other half takes the NEXT output plane (rows = (plane, co)), K then spans
+// the 4 input planes the plane pair touches (36 = 9 k-steps, 27 of the 36 products per row are real).  C_out == 16: K = 27
+// padded to 28 (7 k-steps).  A workgroup loads its input patch (1 channel: a few KB) into LDS once -- 16-byte loads, all of a
+// thread's loads in flight before the first LDS write -- and every wave gathers its voxel-side fragments from it (ds_read_b32,
+// lane -> (voxel, tap)), two tiles at a time; the gate values of a tile pair are requested before its MFMA chain.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct DevM {
   const float *in;
-  int32_t iN, iD, iH, iW, D, H, W;
+  int32_t iN, iD, iH, D, H, W, in_bytes;
   float *out;
   int32_t oN, oD, oH, oW, OD, OH, OW;
   int32_t P;
   int32_t TXT, TY, nty, nzg;        // 16-voxel tiles per row, rows per patch, patches in y, plane groups in z
-  uint32_t magicCols, magicTXT;
+  int32_t colsP, cpr;               // LDS row pitch (floats, multiple of 4) and 16-byte chunks per row
+  int32_t xs, sh;                   // input x of LDS column 0 (a multiple of 4: chunks never straddle x = 0 or x = W) and
+                                    // the column of the first voxel output 0 reads: -P - xs in 0..3
+  uint32_t magicCpr, magicTXT;
   float slope;
   const float *gate; int32_t gN, gD, gH, gW; float gate_slope;
-  const float *bias;
+  int32_t out_bytes, gate_bytes;    // bytes one sample of out / gate spans (buffer ranges)
   int32_t dbg;
 };
 
-template <int CO, bool FLIP>
+// K order: the taps are enumerated as NP * 3 ROWS (zi, dy) of 3 x-taps; lane group kq owns the rows kq, kq + 4, kq + 8 and
+// k-step s = 3 j + dx multiplies x-tap dx of the group's row 4 j + kq.  A lane's three taps of a row are adjacent floats of the
+// patch: ONE ds_read2_b32 + one ds_read_b32 per row instead of three gathers, one address add per row (3 per tile, not 9).
+// With the row pitch = 16 mod 32 floats and an odd TY the rows of the two lane groups of an LDS cycle are 16 banks apart:
+// conflict-free.  EPI: 0 = LeakyReLU(slope) (slope 1: linear), 1 = LeakyReLU' gate on a saved activation -- compiled in, and
+// invalid lanes (tile over-hang) are out-of-range buffer offsets instead of exec-mask regions: the loop body is branch-free
+// and its loads / stores need no vmcnt(0) at a join (round 2's form waited for every tile's STORE to complete).
+template <int CO, bool FLIP, int EPI>
 __global__ __launch_bounds__(256) void c1_mfma_k(DevM p, const float *__restrict__ wgt) {
-  static_assert(CO == 8 || CO == 16, "columns = (plane pair, 8 channels) or 16 channels");
+  static_assert(CO == 8 || CO == 16, "rows = (plane pair, 8 channels) or 16 channels");
   constexpr int NZ = CO == 8 ? 2 : 1;                     // output planes per tile
   constexpr int NP = NZ + 2;                              // input planes per patch
-  constexpr int KS = CO == 8 ? 9 : 7;                     // k-steps of 4 taps
-  constexpr int TPITCH = 20;                              // floats per row of the transpose patch (conflict-free)
-  constexpr int PFM = 4;                                  // patch voxels per thread and plane (rows*cols <= 1024)
+  constexpr int NR = (NP * 3 + 3) / 4;                    // tap rows (zi, dy) per lane group: 3
+  constexpr int KS = NR * 3;                              // k-steps of 4 taps: 9
+  constexpr int NCH = 2;                                  // 16-byte patch chunks per thread and plane (rows * cpr <= 512)
+  constexpr int OOB = (int)0x80000000;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kq = lane >> 4;
-  const int cols = p.TXT * 16 + 2, rows = p.TY + 2;
-  const int plane = rows * cols;
+  const int rows = p.TY + 2;
+  const int plane = rows * p.colsP;
 
   int b = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);     // z-neighbours share input planes: one XCD's L2
   const int zg = b % p.nzg; b /= p.nzg;
@@ -253,121 +267,124 @@ __global__ __launch_bounds__(256) void c1_mfma_k(DevM p, const float *__restrict
   const int n = b / p.nty;
   const int oy0 = typ * p.TY, oz0 = zg * NZ;
 
-  // ---- B fragments: lane (n_col = m, k = 4s + kq)
+  // ---- kernel fragments (the MFMA's A side): lane (row = m, k-step s = 3 j + dx -> tap row 4 j + kq = (zi, dy), x-tap dx)
   float B[KS];
+  int rowoff[NR];                                         // byte offset of the lane's tap row j in the patch (+ voxel m)
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int k = 4 * s + kq;
-    float v = 0.f;
-    if (CO == 8) {
-      const int zi = k / 9, rem = k - zi * 9;             // k = zi*9 + dy*3 + dx, zi in 0..3
-      const int zo = m >> 3, dz = zi - zo;
-      if (dz >= 0 && dz <= 2) {
-        const int tap = dz * 9 + rem;
-        v = wgt[(FLIP ? 26 - tap : tap) * 8 + (m & 7)];
+  for (int j = 0; j < NR; ++j) {
+    const int r = 4 * j + kq;
+    const bool real = r < NP * 3;
+    const int zi = real ? r / 3 : 0, dy = real ? r - zi * 3 : 0;
+    rowoff[j] = (zi * plane + dy * p.colsP + m + p.sh) * 4;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      float v = 0.f;
+      if (real) {
+        const int zo = CO == 8 ? (m >> 3) : 0, dz = zi - zo;
+        if (dz >= 0 && dz <= 2) {
+          const int tap = dz * 9 + dy * 3 + dx;
+          v = wgt[(FLIP ? 26 - tap : tap) * CO + (CO == 8 ? (m & 7) : m)];
+        }
       }
-    } else {
-      if (k < 27) v = wgt[(FLIP ? 26 - k : k) * 16 + m];
+      B[3 * j + dx] = v;
     }
-    B[s] = v;
-  }
-  // ---- A gather offsets inside the patch: tap k -> (zi, dy, dx)
-  int offk[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    int k = 4 * s + kq;
-    if (k >= NP * 9) k = 0;                               // padded k-step (its B is zero): any finite value
-    const int zi = k / 9, rem = k - zi * 9, dy = rem / 3, dx = rem - dy * 3;
-    offk[s] = zi * plane + dy * cols + dx + m;
   }
 
-  // ---- load the patch: NP planes x rows x cols, zeros outside the input (padding / volume border).  All of a
-  // thread's loads are issued before the first LDS write: one memory round trip per workgroup, not one per element.
+  // ---- load the patch: NP planes x rows x colsP, zeros outside the input (padding / volume border).  One 16-byte load per
+  // chunk (4 x-consecutive voxels of the 1-channel input; any 4-byte alignment), every load of the thread issued before the
+  // first LDS write: one memory round trip per workgroup.
   {
-    const int rc = rows * cols;                            // host: rc <= PFM * 256
-    float pf[NP][PFM];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
+    const int nchunk = rows * p.cpr;                       // host: <= NCH * 256
+    u32x4 pf[NP][NCH];
 #pragma unroll
-    for (int i = 0; i < PFM; ++i) {
-      const int r2 = tid + i * 256;
-      const int r = (int)__umulhi((uint32_t)r2, p.magicCols), cx = r2 - r * cols;
-      const int iy = oy0 - p.P + r, ix = cx - p.P;
-      const bool okxy = r2 < rc && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const float *src = p.in + (n * p.iN + iy * p.iH + ix * p.iW);
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * 256;
+      const int r = (int)__umulhi((uint32_t)id, p.magicCpr), c4 = id - r * p.cpr;
+      const int iy = oy0 - p.P + r;
+      const int ix0 = p.xs + 4 * c4;                       // W and xs are multiples of 4: a chunk is inside the row or outside
+      const bool okxy = id < nchunk && (unsigned)iy < (unsigned)p.H && (unsigned)ix0 < (unsigned)p.W;
+      const int base = (n * p.iN + iy * p.iH + ix0) * 4;
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) {
         const int iz = oz0 - p.P + pl;
-        pf[pl][i] = (okxy && (unsigned)iz < (unsigned)p.D && !(p.dbg & 4)) ? src[iz * p.iD] : 0.f;
+        const int off = (okxy && (unsigned)iz < (unsigned)p.D && !(p.dbg & 4)) ? base + iz * p.iD * 4 : OOB;
+        pf[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
       }
     }
 #pragma unroll
-    for (int i = 0; i < PFM; ++i) {
-      const int r2 = tid + i * 256;
-      if (r2 < rc) {
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * 256;
+      if (id < nchunk) {
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) lds[pl * plane + r2] = pf[pl][i];
+        for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x4 *>(lds + pl * plane + id * 4) = pf[pl][i];
       }
     }
   }
   __syncthreads();
 
-  float *tp = lds + ((NP * plane + 3) & ~3) + wave * (16 * TPITCH);
-  const int ti = lane >> 2, tcq = lane & 3;               // transposed role: voxel of the tile, channel quad
-  const int zo = CO == 8 ? (tcq >> 1) : 0, co0 = CO == 8 ? 4 * (tcq & 1) : 4 * tcq;
+  // lane's output role: voxel m of the tile, channels co0 .. co0 + 3 of output plane oz0 + zo
+  const int zo = CO == 8 ? (kq >> 1) : 0, co0 = CO == 8 ? 4 * (kq & 1) : 4 * kq;
+  const int oz = oz0 + zo;
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)(p.out + (size_t)n * p.oN), 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.gate + (size_t)n * p.gN), 0, EPI == 1 ? p.gate_bytes : 0, 0x00020000);
+  const bool zok = oz < p.OD && !(p.dbg & 1);
+  const int obase = (oz * p.oD + oy0 * p.oH + m * p.oW + co0) * 4;          // + trow * oH * 4 + tcol * 16 * oW * 4
+  const int gbase = EPI == 1 ? (oz * p.gD + oy0 * p.gH + m * p.gW + co0) * 4 : 0;
   const int ntiles = (p.dbg & 2) ? 0 : p.TXT * p.TY;
-  // two tiles per iteration: their MFMA chains (each a dependent chain on its own accumulator) and LDS round
-  // trips interleave, so one wave keeps the matrix pipe fed while the other tile's operands are in flight
-  auto tile_src = [&](int t, int &trow, int &tcol) -> const float * {
-    trow = p.TXT == 1 ? t : (int)__umulhi((uint32_t)t, p.magicTXT);   // magic(1) overflows
-    tcol = t - trow * p.TXT;
-    return lds + trow * cols + tcol * 16;
-  };
-  auto epilogue = [&](const f32x4 &acc, int trow, int tcol) {
-    // C/D map: col = lane&15, row = 4*(lane>>4)+reg  ->  lane (voxel ti, channels 4*tcq..)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) tp[(kq * 4 + q) * TPITCH + m] = acc[q];
-    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): this wave's own LDS writes have landed
-    const float4 v4 = *reinterpret_cast<const float4 *>(tp + ti * TPITCH + tcq * 4);
-    const int ox = tcol * 16 + ti, oy = oy0 + trow, oz = oz0 + zo;
-    if (ox < p.OW && oy < p.OH && oz < p.OD && !(p.dbg & 1)) {
-      float v[4] = {v4.x, v4.y, v4.z, v4.w};
-      if (p.bias) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] += p.bias[co0 + c];
-      }
-      if (p.gate) {
-        const float4 g4 = *reinterpret_cast<const float4 *>(p.gate + (n * p.gN + oz * p.gD + oy * p.gH + ox * p.gW + co0));
-        v[0] = g4.x > 0.f ? v[0] : p.gate_slope * v[0];
-        v[1] = g4.y > 0.f ? v[1] : p.gate_slope * v[1];
-        v[2] = g4.z > 0.f ? v[2] : p.gate_slope * v[2];
-        v[3] = g4.w > 0.f ? v[3] : p.gate_slope * v[3];
-      }
-      if (p.slope != 1.f) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : p.slope * v[c];
-      }
-      *reinterpret_cast<float4 *>(p.out + (n * p.oN + oz * p.oD + oy * p.oH + ox * p.oW + co0)) =
-          make_float4(v[0], v[1], v[2], v[3]);
-    }
-  };
+  const char *const ldsb = reinterpret_cast<const char *>(lds);
+  // two tiles per iteration (tiles t and t + 4; a wave walks t = wave, wave + 8, ...): their MFMA chains -- each a dependent
+  // chain on its own accumulator -- interleave.  (trow, tcol) advance as scalars.
+  int tr0 = 0, tc0 = wave;
+  while (tc0 >= p.TXT) { tc0 -= p.TXT; ++tr0; }
   for (int t = wave; t < ntiles; t += 8) {                // wave-uniform
-    const int t2 = t + 4;
-    const bool two = t2 < ntiles;
-    int r0, c0, r1, c1;
-    const float *s0 = tile_src(t, r0, c0);
-    const float *s1 = tile_src(two ? t2 : t, r1, c1);
+    int tr1 = tr0, tc1 = tc0 + 4;
+    while (tc1 >= p.TXT) { tc1 -= p.TXT; ++tr1; }
+    const bool two = t + 4 < ntiles;
+    if (!two) { tr1 = tr0; tc1 = tc0; }
+    const bool ok0 = zok && tc0 * 16 + m < p.OW && oy0 + tr0 < p.OH;
+    const bool ok1 = zok && two && tc1 * 16 + m < p.OW && oy0 + tr1 < p.OH;
+    int oo0 = ok0 ? obase + (tr0 * p.oH + tc0 * 16 * p.oW) * 4 : OOB, oo1 = ok1 ? obase + (tr1 * p.oH + tc1 * 16 * p.oW) * 4 : OOB;
+    u32x4 g0 = {0u, 0u, 0u, 0u}, g1 = g0;
+    if (EPI == 1) {                                       // requested ahead of the MFMA chain
+      const int go0 = ok0 ? gbase + (tr0 * p.gH + tc0 * 16 * p.gW) * 4 : OOB, go1 = ok1 ? gbase + (tr1 * p.gH + tc1 * 16 * p.gW) * 4 : OOB;
+      g0 = __builtin_amdgcn_raw_buffer_load_b128(grs, go0, 0, 0);
+      g1 = __builtin_amdgcn_raw_buffer_load_b128(grs, go1, 0, 0);
+    }
+    const int tb0 = (tr0 * p.colsP + tc0 * 16) * 4, tb1 = (tr1 * p.colsP + tc1 * 16) * 4;
     float a0[KS], a1[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) { a0[s] = s0[offk[s]]; a1[s] = s1[offk[s]]; }
-    __builtin_amdgcn_sched_barrier(0);                    // (all 2 KS reads in flight before the first MFMA: left alone, the
+    for (int j = 0; j < NR; ++j) {
+      const float *s0 = reinterpret_cast<const float *>(ldsb + rowoff[j] + tb0), *s1 = reinterpret_cast<const float *>(ldsb + rowoff[j] + tb1);
+      a0[3 * j] = s0[0]; a0[3 * j + 1] = s0[1]; a0[3 * j + 2] = s0[2];
+      a1[3 * j] = s1[0]; a1[3 * j + 1] = s1[1]; a1[3 * j + 2] = s1[2];
+    }
+    __builtin_amdgcn_sched_barrier(0);                    // (every read in flight before the first MFMA: left alone, the
                                                           // scheduler sinks each read next to its MFMA -- ds_read, lgkmcnt(0), MFMA)
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], B[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], B[s], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(B[s], a0[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(B[s], a1[s], acc1, 0, 0, 0);
     }
-    epilogue(acc0, r0, c0);
-    if (two) epilogue(acc1, r1, c1);
+    u32x4 o0, o1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v0 = acc0[c], v1 = acc1[c];
+      if (EPI == 1) {
+        v0 = __uint_as_float(g0[c]) > 0.f ? v0 : p.gate_slope * v0;
+        v1 = __uint_as_float(g1[c]) > 0.f ? v1 : p.gate_slope * v1;
+      } else {
+        v0 = v0 > 0.f ? v0 : p.slope * v0;                // (slope 1: the same value either way)
+        v1 = v1 > 0.f ? v1 : p.slope * v1;
+      }
+      o0[c] = __float_as_uint(v0); o1[c] = __float_as_uint(v1);
+    }
+    asm volatile("" : "+v"(oo0), "+v"(oo1));
+    __builtin_amdgcn_raw_buffer_store_b128(o0, ors, oo0, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(o1, ors, oo1, 0, 0);
+    tc0 += 8;
+    while (tc0 >= p.TXT) { tc0 -= p.TXT; ++tr0; }
   }
 }
 
@@ -431,30 +448,51 @@ template <int CO, bool FLIP>
 int run_mfma(const Dev &q, int N, hipStream_t st, bool dry) {
   constexpr int NZ = CO == 8 ? 2 : 1, NP = NZ + 2;
   DevM p{};
-  p.in = q.in; p.iN = q.iN; p.iD = q.iD; p.iH = q.iH; p.iW = q.iW; p.D = q.D; p.H = q.H; p.W = q.W;
+  if (q.iW != 1 || q.W % 4) return TEM_EUNSUPPORTED;      // 16-byte loads of 4 x-consecutive voxels, never across a row end
+  p.in = q.in; p.iN = q.iN; p.iD = q.iD; p.iH = q.iH; p.D = q.D; p.H = q.H; p.W = q.W;
+  {
+    const int64_t span = ((int64_t)(N - 1) * q.iN + (int64_t)(q.D - 1) * q.iD + (int64_t)(q.H - 1) * q.iH + q.W) * 4;
+    if (span >= ((int64_t)1 << 31)) return TEM_EUNSUPPORTED;
+    p.in_bytes = (int)span;
+  }
   p.out = q.out; p.oN = q.oN; p.oD = q.oD; p.oH = q.oH; p.oW = q.oW; p.OD = q.OD; p.OH = q.OH; p.OW = q.OW;
   p.P = q.P; p.slope = q.slope; p.gate = q.gate; p.gN = q.gN; p.gD = q.gD; p.gH = q.gH; p.gW = q.gW;
-  p.gate_slope = q.gate_slope; p.bias = q.bias; p.dbg = q.dbg;
+  p.gate_slope = q.gate_slope; p.dbg = q.dbg;
+  if (q.bias) return TEM_EUNSUPPORTED;                    // (no one-channel layer of the path has a bias: the VALU form takes it)
+  if (q.gate && q.slope != 1.f) return TEM_EUNSUPPORTED;  // compiled epilogues: LeakyReLU, or the gate
+  {
+    const int64_t ospan = ((int64_t)(q.OD - 1) * q.oD + (int64_t)(q.OH - 1) * q.oH + (int64_t)(q.OW - 1) * q.oW + CO) * 4;
+    const int64_t gspan = q.gate ? ((int64_t)(q.OD - 1) * q.gD + (int64_t)(q.OH - 1) * q.gH + (int64_t)(q.OW - 1) * q.gW + CO) * 4 : 0;
+    if (ospan >= ((int64_t)1 << 31) || gspan >= ((int64_t)1 << 31)) return TEM_EUNSUPPORTED;
+    p.out_bytes = (int)ospan; p.gate_bytes = (int)gspan;
+  }
   p.TXT = (p.OW + 15) / 16;
-  // rows per patch: ~32 tiles per workgroup (8 per wave) keeps the patch load + barrier a small share
-  p.TY = 32 / p.TXT;
-  if (p.TY < 1) p.TY = 1;
+  p.xs = p.P <= 0 ? (-p.P / 4) * 4 : -((p.P + 3) / 4) * 4;  // floor(-P / 4) * 4
+  p.sh = -p.P - p.xs;
+  p.colsP = p.TXT * 16 + 16;                              // columns sh .. sh + 16 TXT + 1 are read (sh <= 3); pitch = 16 mod 32
+  p.cpr = p.colsP / 4;
+  // rows per patch: ~64 tiles per workgroup (16 per wave; the patch's two halo rows are (TY + 2) / TY of the input reads),
+  // bounded by the loader's two chunks per thread and plane
+  p.TY = (64 + p.TXT - 1) / p.TXT;
   if (p.TY > p.OH) p.TY = p.OH;
-  while (p.TY > 1 && (p.TY + 2) * (p.TXT * 16 + 2) > 4 * 256) --p.TY;      // the loader holds 4 voxels per thread and plane
-  if ((p.TY + 2) * (p.TXT * 16 + 2) > 4 * 256) return TEM_EUNSUPPORTED;
+  while (p.TY > 1 && (p.TY + 2) * p.cpr > 2 * 256) --p.TY;
+  if ((p.TY + 2) * p.cpr > 2 * 256) return TEM_EUNSUPPORTED;
+  p.nty = (p.OH + p.TY - 1) / p.TY;
+  p.TY = (p.OH + p.nty - 1) / p.nty;                       // even bands
+  if (!(p.TY & 1) && (p.TY + 3) * p.cpr <= 2 * 256) ++p.TY;   // odd: tap rows of neighbouring planes 16 banks apart
   p.nty = (p.OH + p.TY - 1) / p.TY;
   p.nzg = (p.OD + NZ - 1) / NZ;
-  p.magicCols = magic_for(p.TXT * 16 + 2);
+  p.magicCpr = magic_for(p.cpr);
   p.magicTXT = magic_for(p.TXT);
-  const size_t patch = (size_t)NP * (p.TY + 2) * (p.TXT * 16 + 2);
-  const size_t lds_bytes = (((patch + 3) & ~(size_t)3) + 4 * 16 * 20) * 4;
+  const size_t lds_bytes = (size_t)NP * (p.TY + 2) * p.colsP * 4;
   if (lds_bytes > 64 * 1024) return TEM_EUNSUPPORTED;
   if (dry) {
-    if (g_name) snprintf(g_name, g_name_len, "c1_mfma_k<%d, %s>", CO, FLIP ? "true" : "false");
+    if (g_name) snprintf(g_name, g_name_len, "c1_mfma_k<%d, %s, %d>", CO, FLIP ? "true" : "false", q.gate ? 1 : 0);
     return TEM_OK;
   }
   const int nblocks = N * p.nty * p.nzg;
-  hipLaunchKernelGGL((c1_mfma_k<CO, FLIP>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, q.w);
+  if (q.gate) hipLaunchKernelGGL((c1_mfma_k<CO, FLIP, 1>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, q.w);
+  else hipLaunchKernelGGL((c1_mfma_k<CO, FLIP, 0>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, q.w);
   TEM_CHECK_LAUNCH();
   return TEM_OK;
 }
@@ -496,10 +534,14 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   if (CI == ci && CO == co) return flip ? run<ci, co, true, pf>(p, N, st, dry) : run<ci, co, false, pf>(p, N, st, dry);
   static int use_mfma = -1;
   if (use_mfma < 0) use_mfma = tem_env_int("TEM_C1_MFMA", 1);
-  if (use_mfma && CI == 1 && CO == 8)      // g.c0, d.d1a forward
-    return flip ? run_mfma<8, true>(p, N, st, dry) : run_mfma<8, false>(p, N, st, dry);
-  if (use_mfma && CI == 1 && CO == 16)     // input-gradient of g.f2 (gated by f1)
-    return flip ? run_mfma<16, true>(p, N, st, dry) : run_mfma<16, false>(p, N, st, dry);
+  if (use_mfma && CI == 1 && CO == 8) {    // g.c0, d.d1a forward
+    const int rc = flip ? run_mfma<8, true>(p, N, st, dry) : run_mfma<8, false>(p, N, st, dry);
+    if (rc != TEM_EUNSUPPORTED) return rc;  // (odd row lengths / strided x: the VALU form below)
+  }
+  if (use_mfma && CI == 1 && CO == 16) {   // input-gradient of g.f2 (gated by f1)
+    const int rc = flip ? run_mfma<16, true>(p, N, st, dry) : run_mfma<16, false>(p, N, st, dry);
+    if (rc != TEM_EUNSUPPORTED) return rc;
+  }
   C1_CASE(1, 8, 3)
   C1_CASE(1, 16, 3)
   C1_CASE(16, 1, 6)      // g.f2 forward

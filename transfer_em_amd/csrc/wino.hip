@@ -104,19 +104,20 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   const int ntile = p.BY * p.BX;
 
   // ---- LDS-DMA: byte offset of the lane's chunk inside a z-plane of the source view, relative to the sub-image's first
-  // channel (the same for every sub-image and plane; recomputed per call -- a descriptor kept in registers across the
-  // step would be spilled, and its reload waits for the DMA in flight); out of range = zero padding / slot padding
+  // channel (the same for every sub-image, plane and step): computed ONCE and pinned in 2 NI VGPRs.  [Round 2 recomputed
+  // them in every step -- ~40 vector instructions per chunk (index split, swizzle, bounds, two 64-bit multiply-adds),
+  // 160 per step and wave -- on the belief that a value held across the step would be spilled; the kernels use ~160 of the
+  // 256 VGPRs two waves per SIMD allow, and on this chip a vector instruction costs matrix-pipe time: v_mfma_f32 and VALU
+  // issue serialise (tests/tools/issue_probe.hip: 4 MFMA + 16 v_add_u32 = 211 cycles, 128 + 76 apart).]
+  // Out of range = zero padding / slot padding.
   const bool two_in = p.in1 != p.in0;                      // kernel-uniform
   const float *const in0n = p.in0 + (size_t)n * p.i0N, *const in1n = p.in1 + (size_t)n * p.i1N;
-  auto dma_plane = [&](int iz, int slot) {                 // input plane iz -> ring slot (zeros outside the input)
-    const bool zok = (unsigned)iz < (unsigned)p.D;
-    const int izc = zok ? iz : 0;
+  int voff0[NI], voff1[NI];
+  {
     const int iy0 = oy0 - p.P, ix0 = ox0 - p.P;
-    int voff0[NI], voff1[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      int sp = (wave + 8 * i) * 64 + lane;
-      asm volatile("" : "+v"(sp));
+      const int sp = (wave + 8 * i) * 64 + lane;
       const bool ex = sp < p.PLC;
       const int spc = ex ? sp : 0;
       const int cpos = spc & 1, ve = spc >> 1;
@@ -127,7 +128,12 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
       const bool ok = ex && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       voff0[i] = ok ? (iy * p.i0H + ix * p.i0W + c) * 4 : (int)0x80000000;
       voff1[i] = ok ? (iy * p.i1H + ix * p.i1W + c) * 4 : (int)0x80000000;
+      asm volatile("" : "+v"(voff0[i]), "+v"(voff1[i]));     // opaque: held, not rematerialised inside the step loop
     }
+  }
+  auto dma_plane = [&](int iz, int slot) {                 // input plane iz -> ring slot (zeros outside the input)
+    const bool zok = (unsigned)iz < (unsigned)p.D;
+    const int izc = zok ? iz : 0;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       char *const dst = ring + slot * p.slotb + h * p.subb;

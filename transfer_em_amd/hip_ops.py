@@ -182,7 +182,7 @@ def conv_launch(name, in0, w, out0, k, s=1, p=0, *, is3d=True, in1=None, out1=No
     return Launch(fn, (C.byref(a),), name, keep + [a], meta)
 
 
-MAX_SLABS = 1024
+MAX_SLABS = 8192
 
 
 class GradWorkspace:
