@@ -90,8 +90,13 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   const int m = lane & 15, q = lane >> 4;
   const int grp = PAIR ? wave : (NB == 1 ? wave >> 1 : wave >> 2);   // 16-tile row block
   const int nb = NB == 1 ? 0 : (wave >> 1) & 1;              // column block
-  const int zb = PAIR ? (m >> 3) : (wave & 1);               // output plane of the step: per wave, or (PAIR) per column half
-  const int co = PAIR ? (m & 7) : nb * 16 + m;               // this lane's output channel (C/D column)
+  // C/D roles.  The kernel fragments are the MFMA's A side and the transformed input its B side: D rows = output channels,
+  // columns = tiles, so a lane ends up with FOUR CONSECUTIVE CHANNELS (rows 4 q .. 4 q + 3) of ONE tile (column m) -- its 2x2
+  // output voxels leave as four 16-byte stores and need four gate / keep-byte fetches and four offset computations (round 2
+  // had tiles as rows: 16 4-byte stores and 16 fetches per lane and plane, ~200 vector instructions per step more -- which
+  // on this chip is matrix-pipe time: VALU and fp32 MFMA issue serialise).
+  const int zb = PAIR ? (q >> 1) : (wave & 1);               // output plane of the step: per wave, or (PAIR) per row half
+  const int co = PAIR ? 4 * (q & 1) : nb * 16 + 4 * q;       // this lane's first output channel (it owns co .. co + 3)
   float *const uld = reinterpret_cast<float *>(ring + 4 * p.slotb);
 
   int seg = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -173,18 +178,19 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   const Ep32 &ep = p.ep;
   float *const out0n = p.out0 + (size_t)n * p.o0N, *const out1n = EP == 2 ? p.out1 + (size_t)n * p.o1N : nullptr;
   const float *const gaten = EP >= 1 ? ep.gate + (size_t)n * ep.gN : nullptr;
-  const bool in0c = EP != 2 || co < p.CO0;                   // this lane's channel goes to out0 (with the full epilogue)
-  // The epilogue runs 16 times per lane and plane on the vector pipe the transforms need: everything that does not depend on
-  // the output voxel is a lane constant or a scalar.  The lane's destination tensor (EP 2: out0 or out1 by its channel) is
-  // chosen once; gate values and keep bytes come through buffer descriptors -- per load ONE select (offset or out-of-range
-  // = zero), the 2x2 voxel's displacement in the scalar offset; the keep bit of a lane is always bit co & 7 of its byte.
+  const bool in0c = EP != 2 || co < p.CO0;                   // this lane's channels go to out0 (with the full epilogue)
+  // The epilogue runs on the vector pipe the transforms need: everything that does not depend on the output voxel is a lane
+  // constant or a scalar.  The lane's destination tensor (EP 2: out0 or out1 by its channel quad) is chosen once; gate
+  // values (16 bytes = the lane's 4 channels) and keep bytes come through buffer descriptors -- per fetch ONE select (offset
+  // or out-of-range = zero), the 2x2 voxel's displacement in the scalar offset; the keep bits of the lane are bits
+  // (co & 4) .. (co & 4) + 3 of its voxel's byte.
   float *const obase = EP == 2 ? (in0c ? out0n : out1n) : out0n;      // (EP 0, 1: wave-uniform -- scalar base + 32-bit offset)
   const int oco = in0c ? co : co - p.CO0;
   const int oD = in0c ? p.o0D : p.o1D, oH = in0c ? p.o0H : p.o1H, oW = in0c ? p.o0W : p.o1W;
   const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)gaten, 0, EP >= 1 ? ep.gbytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void *)ep.keep_mask, 0, EP == 2 ? ep.mbytes : 0, 0x00020000);
   const int mpv = EP == 2 ? p.CO0 >> 3 : 0;                  // mask bytes per voxel
-  const uint32_t kbit = 1u << (co & 7);
+  const int kshift = co & 4;
   int gso[4], mso[4], oso[4];                                // scalar offsets of the 2x2 voxels (bytes)
 #pragma unroll
   for (int o4 = 0; o4 < 4; ++o4) {
@@ -213,52 +219,49 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   // partner runs its epilogue at the END of its step -- the two pipes of a SIMD stay busy across the step boundary.
   const bool late = (p.dbg & 32) ? wave >= 4 : false;      // measured: no gain (the barriers re-serialise the waves; one wave alone fills 45 % of the matrix pipe); kept for experiments
   f32x4 acc[16];
-  float gv[16];                                            // gate values / keep-bit bytes of the lane's 16 outputs
-  uint32_t kb[16];                                         //   (4 tiles x 2x2 voxels of one plane), fetched a step ahead of use
-  // per tile r of the lane (tiles 4q .. 4q+3 of the row block): its output voxel (0, 0) as (oy << 16 | ox) and the validity
-  // of its 2x2 voxels -- computed once (the tiles do not move along z); offsets are a few multiply-adds from these
-  uint32_t tyx[4], tok4 = 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int t = grp * 16 + 4 * q + r;
+  f32x4 gv[4];                                             // gate values / keep bytes of the lane's 4 output voxels (2x2 of its tile, its 4
+  uint32_t kb[4];                                          //   channels), fetched a step ahead of use
+  // the lane's tile (column m of the row block): its output voxel (0, 0) and the validity of its 2x2 voxels -- computed once
+  // (the tiles do not move along z); offsets are a few multiply-adds from these
+  uint32_t tyx, tok4 = 0;
+  {
+    const int t = grp * 16 + m;
     const int ty = (int)fdiv((uint32_t)t, (uint32_t)p.BX, p.magicBX), tx = t - ty * p.BX;
     const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
     const bool tok = co < CO && t < ntile;
 #pragma unroll
-    for (int o4 = 0; o4 < 4; ++o4) tok4 |= ((tok && oy + (o4 >> 1) < p.OH && ox + (o4 & 1) < p.OW) ? 1u : 0u) << (4 * r + o4);
-    tyx[r] = ((uint32_t)oy << 16) | (uint32_t)ox;
+    for (int o4 = 0; o4 < 4; ++o4) tok4 |= ((tok && oy + (o4 >> 1) < p.OH && ox + (o4 & 1) < p.OW) ? 1u : 0u) << o4;
+    tyx = ((uint32_t)oy << 16) | (uint32_t)ox;
   }
-  auto tile_geom = [&](int r, int oz, int &o0, int &go, int &mb, uint32_t &okm) {
-    uint32_t yx = tyx[r];
+  auto tile_geom = [&](int oz, int &o0, int &go, int &mb, uint32_t &okm) {
+    uint32_t yx = tyx;
     asm volatile("" : "+v"(yx));                             // per-use recompute: no per-output offsets hoisted out of the step loop
     const int oy = (int)(yx >> 16), ox = (int)(yx & 0xffffu);
-    okm = oz < p.OD ? (tok4 >> (4 * r)) & 15u : 0u;
+    okm = oz < p.OD ? tok4 : 0u;
     o0 = oz * oD + oy * oH + ox * oW + oco;
     go = EP >= 1 ? (oz * ep.gD + oy * ep.gH + ox * ep.gW + co) * 4 : 0;
     mb = EP == 2 ? (int)(((((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint32_t)mpv) + (co >> 3) : 0;
   };
   auto fetch_ep = [&](int oz) {
+    int o0, go, mb;
+    uint32_t okm;
+    tile_geom(oz, o0, go, mb, okm);
+    if (!in0c) okm = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int o0, go, mb;
-      uint32_t okm;
-      tile_geom(r, oz, o0, go, mb, okm);
-      if (!in0c) okm = 0;
-#pragma unroll
-      for (int o4 = 0; o4 < 4; ++o4) {
-        const bool okf = (okm >> o4) & 1u;
-        int goff = okf ? go : (int)0x80000000;
-        asm volatile("" : "+v"(goff));
-        gv[r * 4 + o4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(grs, goff, gso[o4], 0));
-        if (EP == 2) {
-          int moff = okf ? mb : (int)0x80000000;
-          asm volatile("" : "+v"(moff));
-          kb[r * 4 + o4] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(mrs, moff, mso[o4], 0);
-        }
+    for (int o4 = 0; o4 < 4; ++o4) {
+      const bool okf = (okm >> o4) & 1u;
+      int goff = okf ? go : (int)0x80000000;
+      asm volatile("" : "+v"(goff));
+      const u32x4 g4 = __builtin_amdgcn_raw_buffer_load_b128(grs, goff, gso[o4], 0);
+      gv[o4] = f32x4{__uint_as_float(g4.x), __uint_as_float(g4.y), __uint_as_float(g4.z), __uint_as_float(g4.w)};
+      if (EP == 2) {
+        int moff = okf ? mb : (int)0x80000000;
+        asm volatile("" : "+v"(moff));
+        kb[o4] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(mrs, moff, mso[o4], 0) >> kshift;
       }
     }
   };
-  // output transform A^T M A on (y, x) and epilogue of plane oz; lane = (channel m, tiles 4q .. 4q+3 of the row block: the
+  // output transform A^T M A on (y, x) and epilogue of plane oz; lane = (tile m of the row block, channels co .. co + 3: the
   // f32x4 components of the accumulators)
   auto finish = [&](int oz) {
     f32x4 yx[4][2], yy[2][2];
@@ -266,27 +269,31 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     for (int a = 0; a < 4; ++a) at4(acc[a * 4 + 0], acc[a * 4 + 1], acc[a * 4 + 2], acc[a * 4 + 3], yx[a][0], yx[a][1]);
 #pragma unroll
     for (int b = 0; b < 2; ++b) at4(yx[0][b], yx[1][b], yx[2][b], yx[3][b], yy[0][b], yy[1][b]);
+    int o0, go, mb;
+    uint32_t okm;
+    tile_geom(oz, o0, go, mb, okm);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int o0, go, mb;
-      uint32_t okm;
-      tile_geom(r, oz, o0, go, mb, okm);
+    for (int o4 = 0; o4 < 4; ++o4) {
+      const bool ok = (okm >> o4) & 1u;
+      f32x4 val = yy[o4 >> 1][o4 & 1];
 #pragma unroll
-      for (int o4 = 0; o4 < 4; ++o4) {
-        const bool ok = (okm >> o4) & 1u;
-        float val = yy[o4 >> 1][o4 & 1][r];
-        if (EP == 0) val = fmaxf(val, ep.slope * val);           // LeakyReLU for 0 <= slope <= 1 (host): max instead of compare + select
+      for (int r = 0; r < 4; ++r) {
+        if (EP == 0) val[r] = fmaxf(val[r], ep.slope * val[r]);         // LeakyReLU for 0 <= slope <= 1 (host): max instead of compare + select
         if (EP >= 1 && in0c) {
-          val = gv[r * 4 + o4] > 0.f ? val : ep.gate_slope * val;
-          if (EP == 2) val = (kb[r * 4 + o4] & kbit) ? 2.f * val : 0.f;
+          val[r] = gv[o4][r] > 0.f ? val[r] : ep.gate_slope * val[r];
+          if (EP == 2) val[r] = ((kb[o4] >> r) & 1u) ? 2.f * val[r] : 0.f;
         }
-        if (EP == 2 || STREAM) {                             // (32 input channels: measured 5 % slower with buffer stores)
-          if (ok) obase[o0 + (o4 >> 1) * oH + (o4 & 1) * oW] = val;
-        } else {
-          int so = ok ? o0 * 4 : (int)0x80000000;
-          asm volatile("" : "+v"(so));
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ors, so, oso[o4], 0);
-        }
+      }
+      if (EP == 2 || STREAM) {                               // (32 input channels: measured 5 % slower with buffer stores)
+        if (ok) *reinterpret_cast<f32x4 *>(obase + o0 + (o4 >> 1) * oH + (o4 & 1) * oW) = val;
+      } else {
+        // (the voxel's displacement goes into the VECTOR offset, the scalar offset stays 0: a 16-byte buffer store with an
+        // SGPR offset whose data registers the next vector instruction overwrites lost data on gfx950 -- the gated epilogue's
+        // v_pk_mul right behind the store corrupted its second component; hipcc pads that hazard only for immediate offsets)
+        int so = ok ? o0 * 4 + oso[o4] : (int)0x80000000;
+        asm volatile("" : "+v"(so));
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])},
+                                               ors, so, 0, 0);
       }
     }
   };
@@ -340,15 +347,20 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
 #pragma unroll
         for (int pt = 0; pt < 16; ++pt) uf[pt] = *reinterpret_cast<const f32x2 *>(uh + pt * 128);
 #pragma unroll
-        for (int pt = 0; pt < 16; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[pt >> 2][pt & 3].x, uf[pt].x, acc[pt], 0, 0, 0);
+        for (int pt = 0; pt < 16; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[pt].x, v[pt >> 2][pt & 3].x, acc[pt], 0, 0, 0);
 #pragma unroll
-        for (int pt = 0; pt < 16; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[pt >> 2][pt & 3].y, uf[pt].y, acc[pt], 0, 0, 0);
+        for (int pt = 0; pt < 16; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[pt].y, v[pt >> 2][pt & 3].y, acc[pt], 0, 0, 0);
       }
     }
     STAMP(1);                                              // reads + transforms + MFMAs (+ ring hand-over)
 
     if (!late) finish(oz);
     STAMP(3);                                              // epilogue (early waves)
+    // every wave's DMA of the next step's planes (and, streamed kernels, of the next kernel chunk) has LANDED before the
+    // barrier lets anyone read them.  Explicit: until round 3 this held only because hipcc puts vmcnt(0) in front of the first
+    // LDS read that follows an LDS-DMA in program order -- which drained the fetch inside the same step by accident of the
+    // schedule; the 8 -> 8 gated variant, rescheduled by the new epilogue, read planes another wave's DMA had not delivered.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   if (late && nsteps > 0) finish(2 * (tz1 - 1) + zb);

@@ -87,15 +87,14 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   // ---- LDS-DMA of the input planes (as wino.hip; the sub-images are 64 bytes apart modulo 128 here, see below)
   const bool two_in = p.in1 != p.in0;
   const float *const in0n = p.in0 + (size_t)n * p.i0N, *const in1n = p.in1 + (size_t)n * p.i1N;
-  auto dma_plane = [&](int iz, int slot) {
-    const bool zok = (unsigned)iz < (unsigned)p.D;
-    const int izc = zok ? iz : 0;
+  // (chunk offsets inside a plane: computed once and held -- see wino.hip; per step they cost ~40 vector instructions per
+  // chunk, and vector instructions are matrix-pipe time on this chip)
+  int voff0[NI], voff1[NI];
+  {
     const int iy0 = oy0 - p.P, ix0 = ox0 - p.P;
-    int voff0[NI], voff1[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      int sp = (wave + 8 * i) * 64 + lane;
-      asm volatile("" : "+v"(sp));
+      const int sp = (wave + 8 * i) * 64 + lane;
       const bool ex = sp < p.PLC;
       const int spc = ex ? sp : 0;
       const int cpos = spc & 1, ve = spc >> 1;
@@ -106,7 +105,12 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
       const bool ok = ex && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       voff0[i] = ok ? (iy * p.i0H + ix * p.i0W + c) * 4 : (int)0x80000000;
       voff1[i] = ok ? (iy * p.i1H + ix * p.i1W + c) * 4 : (int)0x80000000;
+      asm volatile("" : "+v"(voff0[i]), "+v"(voff1[i]));
     }
+  }
+  auto dma_plane = [&](int iz, int slot) {
+    const bool zok = (unsigned)iz < (unsigned)p.D;
+    const int izc = zok ? iz : 0;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       char *const dst = ring + slot * p.slotb + h * p.subb;
@@ -294,6 +298,9 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
           }
         }
       }
+      // (wino.hip: every wave's plane DMA has landed before the barrier lets anyone read the planes -- explicit, not by the
+      // accident of a compiler-placed vmcnt(0); the gradient prefetch in flight is waited for with it: it is consumed next)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   };

@@ -6,6 +6,7 @@ namespace wino {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t fdiv(uint32_t x, uint32_t d, uint32_t magic) { return d == 1 ? x : __umulhi(x, magic); }
 
