@@ -71,7 +71,11 @@ struct Dev {
 // workgroup owns 32 tiles.  C_in = 32 (STREAM): the transformed kernel (98 / 196 KB) does not fit beside the ring; it
 // streams through two 16 / 32 KB LDS buffers in (z tap, channel-half pair) chunks, one chunk ahead of its use.  32 -> 16:
 // the ring of a 32-channel input leaves room for 48 tiles (three row blocks; the fourth pair of waves idles along).
-template <int CI, int CO, int NI, int EP>
+// EE: the LDS image's row pitch in voxels per (row, x parity) = compile time (9 for tile blocks up to 8 wide, 17 up to 16):
+// the 16 raw reads of a (z tap, channel half) are then 4 lane bases + immediates, and the DMA's index split is a constant
+// division (with a run-time pitch every read had its own address add: ~150 vector instructions per step and wave, a quarter
+// of the loop's vector work -- which is matrix-pipe time here).
+template <int CI, int CO, int NI, int EP, int EE>
 __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   constexpr int NH = CI / 8, VB = 32;                        // channel-pair halves = sub-images (8 channels); bytes per sub-image voxel
   constexpr int NB = (CO + 15) / 16;                         // 16-channel column blocks
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
       const bool ex = sp < p.PLC;
       const int spc = ex ? sp : 0;
       const int cpos = spc & 1, ve = spc >> 1;
-      const int ro = (int)fdiv((uint32_t)ve, (uint32_t)p.E, p.magicE), e = ve - ro * p.E;
+      const int ro = ve / EE, e = ve - ro * EE;
       const int o = ro & 1, yr = ro >> 1;
       const int c = (cpos ^ swz(e, yr)) * 4;
       const int iy = iy0 + yr, ix = ix0 + 2 * e + o;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   }
   __syncthreads();
 
-  const int rowb = p.E * VB;                                 // bytes per (yr, o) row of a sub-image
+  constexpr int rowb = EE * VB;                              // bytes per (yr, o) row of a sub-image
   const Ep32 &ep = p.ep;
   float *const out0n = p.out0 + (size_t)n * p.o0N, *const out1n = EP == 2 ? p.out1 + (size_t)n * p.o1N : nullptr;
   const float *const gaten = EP >= 1 ? ep.gate + (size_t)n * ep.gN : nullptr;
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   // A role: this lane's (tile, channel pair) of the wave's row block
   const int tA = min(grp * 16 + m, ntile - 1);
   const int tyA = (int)fdiv((uint32_t)tA, (uint32_t)p.BX, p.magicBX), txA = tA - tyA * p.BX;
-  const int a0 = (4 * tyA * p.E + txA) * VB + (q & 1) * 8;
+  const int a0 = (4 * tyA * EE + txA) * VB + (q & 1) * 8;
   int cs[2][2];                                              // chunk byte offset for (e = tx + a, tile row ty + b)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -449,7 +453,7 @@ static thread_local char *g_name = nullptr;
 static thread_local int g_name_len = 0;
 
 template <int CI, int CO, int NI>
-int plan(Dev &p, double *cost, size_t *lds_bytes) {
+int plan(Dev &p, double *cost, size_t *lds_bytes, int EE) {
   constexpr int NH = CI / 8, NB = (CO + 15) / 16;
   constexpr bool PAIR = CI == 8 && CO == 8;
   const size_t ubytes = CI == 32 ? (size_t)2 * (2 * NB * 16 * 128) * 4                       // streamed: two chunk buffers
@@ -460,7 +464,8 @@ int plan(Dev &p, double *cost, size_t *lds_bytes) {
     for (int bx = 1; bx <= TX && bx <= 64; ++bx) {
       const int nt = by * bx;
       if (nt > (PAIR ? 128 : 64 / NB)) continue;
-      const int E = bx + 1, plv = (2 * by + 2) * 2 * E;
+      if (bx + 1 > EE) continue;                             // the kernel's compile-time row pitch
+      const int E = EE, plv = (2 * by + 2) * 2 * E;
       const int subb = (plv * 32 + 1023) & ~1023, slotb = NH * subb;
       const size_t bytes = (size_t)4 * slotb + ubytes;
       const int ndma = subb / 1024;
@@ -488,21 +493,10 @@ int plan(Dev &p, double *cost, size_t *lds_bytes) {
   return best < 1e300 ? TEM_OK : TEM_EUNSUPPORTED;
 }
 
-template <int CI, int CO, int NI, int EP>
-int run_best(Dev p, hipStream_t st, bool dry) {
-  double c1 = 1e300;
-  size_t lds_bytes = 0;
-  if (plan<CI, CO, NI>(p, &c1, &lds_bytes) != TEM_OK) return TEM_EUNSUPPORTED;
-  p.magicBX = magic_for(p.BX); p.magicE = magic_for(p.E);
-  if (dry) {
-    if (g_name) snprintf(g_name, g_name_len, "wino_conv_k<%d, %d, %d, %d>", CI, CO, NI, EP);
-    return TEM_OK;
-  }
+template <int CI, int CO, int NI, int EP, int EE>
+static int launch(const Dev &p, size_t lds_bytes, hipStream_t st) {
   const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
-  if (p.dbg & 8)
-    fprintf(stderr, "wino<%d,%d,%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI, CO, EP,
-            p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
-  auto kern = wino_conv_k<CI, CO, NI, EP>;
+  auto kern = wino_conv_k<CI, CO, NI, EP, EE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
@@ -512,6 +506,36 @@ int run_best(Dev p, hipStream_t st, bool dry) {
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds_bytes, st, p);
   TEM_CHECK_LAUNCH();
   return TEM_OK;
+}
+
+template <int CI, int CO, int NI, int EP>
+int run_best(Dev p, hipStream_t st, bool dry) {
+  // the compiled row pitches: the cheapest plan wins (ties: the narrower pitch)
+  static int force = -1;
+  if (force < 0) force = tem_env_int("TEM_WINO_EE", 0);
+  const int pitches[2] = {9, 17};      // (11 measured too: never better than 9 on the step's shapes)
+  Dev best = p;
+  double cbest = 1e300;
+  size_t lds_bytes = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (force && pitches[i] != force) continue;
+    Dev q = p;
+    double c = 1e300;
+    size_t l = 0;
+    if (plan<CI, CO, NI>(q, &c, &l, pitches[i]) == TEM_OK && c < cbest) { best = q; cbest = c; lds_bytes = l; }
+  }
+  if (cbest >= 1e300) return TEM_EUNSUPPORTED;
+  p = best;
+  p.magicBX = magic_for(p.BX); p.magicE = magic_for(p.E);
+  if (dry) {
+    if (g_name) snprintf(g_name, g_name_len, "wino_conv_k<%d, %d, %d, %d, %d>", CI, CO, NI, EP, p.E);
+    return TEM_OK;
+  }
+  const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
+  if (p.dbg & 8)
+    fprintf(stderr, "wino<%d,%d,%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI, CO, EP,
+            p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
+  return p.E == 9 ? launch<CI, CO, NI, EP, 9>(p, lds_bytes, st) : launch<CI, CO, NI, EP, 17>(p, lds_bytes, st);
 }
 
 int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {

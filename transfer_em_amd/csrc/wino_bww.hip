@@ -55,7 +55,9 @@ struct BDev {
 // 32 channels on either side: the layer is CIH x NB independent (16-channel input half, 16-channel output block)
 // problems over the same planes -- a wave pair (the two point halves) owns one such combination and fewer tile subsets
 // remain (NS = 4 / (CIH NB)); 32 input channels: 32 tiles per workgroup (the ring of a 32-channel input is twice as big).
-template <int CI, int CO, int NI, bool PAIR>
+// EE: compile-time row pitch of the LDS image (voxels per (row, x parity); 9: tile blocks up to 8 wide, 17: up to 16), as in
+// wino.hip: raw reads become lane bases + immediates.
+template <int CI, int CO, int NI, bool PAIR, int EE>
 __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   constexpr int NH = CI / 8, VB = 32;
   constexpr int MT = CI >= 16 ? 3 : 2;                       // accumulator tiles per point: (tap, ci) row tiles, or types A / B
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
       const bool ex = sp < p.PLC;
       const int spc = ex ? sp : 0;
       const int cpos = spc & 1, ve = spc >> 1;
-      const int ro = (int)fdiv((uint32_t)ve, (uint32_t)p.E, p.magicE), e = ve - ro * p.E;
+      const int ro = ve / EE, e = ve - ro * EE;
       const int o = ro & 1, yr = ro >> 1;
       const int c = cpos * 4;                                // no chunk swizzle here: see the bank note below
       const int iy = iy0 + yr, ix = ix0 + 2 * e + o;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   // rows (channels 0..7 | 8..15, or taps 0 | 1 for C_in 8) x the tiles of lane groups q and q + 1 (two tiles = 64 bytes
   // apart) then covers the 32 banks exactly once.
   const int ciA = CI >= 16 ? 16 * cih + m : (m & 7);          // the lane's input channel (A rows)
-  const int rowb = p.E * VB;
+  constexpr int rowb = EE * VB;
   // tile pair j of the lane: tiles t0 = 8 JW sub + 8 j + 2 q (k-step 2 j, the .x of the packed values) and t0 + 1 (k-step
   // 2 j + 1, .y) -- x neighbours (BX is even): one ds_read2_b32 fetches a raw value of both
   int abase[JW], dybase[JW];                                // byte offset of t0's raw origin inside a plane image; t0's gradient voxel (0,0)
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
     const int t = sub * (8 * JW) + 8 * j + 2 * q;
     const int tc = min(t, ntile - 2);
     const int ty = (int)fdiv((uint32_t)tc, (uint32_t)p.BX, p.magicBX), tx = tc - ty * p.BX;
-    abase[j] = (ciA >> 3) * p.subb + (4 * ty * p.E + tx) * VB + (ciA & 7) * 4;
+    abase[j] = (ciA >> 3) * p.subb + (4 * ty * EE + tx) * VB + (ciA & 7) * 4;
     const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
     dybase[j] = oy * p.dH + ox * p.dW + (PAIR ? (m & 7) + (m >> 3) * p.dD : 16 * nb + m);   // PAIR: column block = output plane
 #pragma unroll
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
 constexpr int LDS_MAX_B = 160 * 1024;
 
 template <int CI, int CO, int NI>
-static int plan_bww(BDev &p, size_t *lds_bytes) {
+static int plan_bww(BDev &p, size_t *lds_bytes, int EE, double *cost) {
   constexpr int NH = CI / 8, MT = CI >= 16 ? 3 : 2;
   constexpr int CIH = CI >= 16 ? CI / 16 : 1, NB = CO / 16 > 0 ? CO / 16 : 1, NC = CIH * NB, TB = CI == 32 ? 32 : 64;
   const int TY = (p.OH + 1) / 2, TX = (p.OW + 1) / 2;
@@ -386,7 +388,8 @@ static int plan_bww(BDev &p, size_t *lds_bytes) {
     for (int bx = 1; bx <= TX && bx <= 64; ++bx) {
       const int nt = by * bx;
       if (nt > TB) continue;
-      const int E = bx + 1, plv = (2 * by + 2) * 2 * E;
+      if (bx + 1 > EE) continue;                                       // the kernel's compile-time row pitch
+      const int E = EE, plv = (2 * by + 2) * 2 * E;
       const int ndma = (plv * 32 + 1023) / 1024;
       if (bx & 1) continue;                                            // tile pairs (t, t + 1) must not wrap rows
       const int subb = ndma * 1024 + 32, slotb = ((NH * subb + 127) / 128) * 128 + (NH == 1 ? 32 : 0);
@@ -406,6 +409,7 @@ static int plan_bww(BDev &p, size_t *lds_bytes) {
         }
       }
     }
+  *cost = best;
   return best < 1e300 ? TEM_OK : TEM_EUNSUPPORTED;
 }
 
@@ -448,14 +452,30 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
   p.NTZ = (p.OD + 1) / 2;
   p.P = a->pd;
   size_t lds_bytes = 0;
-  const int rc = variant == 0 ? plan_bww<8, 8, 2>(p, &lds_bytes) : variant == 1 ? plan_bww<16, 16, 2>(p, &lds_bytes)
-               : variant == 2 ? plan_bww<8, 16, 2>(p, &lds_bytes) : variant == 3 ? plan_bww<16, 32, 2>(p, &lds_bytes)
-               : variant == 4 ? plan_bww<32, 16, 2>(p, &lds_bytes) : plan_bww<32, 32, 2>(p, &lds_bytes);
+  // the two compiled row pitches: the cheaper plan wins (ties: the narrower pitch)
+  int rc = TEM_EUNSUPPORTED;
+  {
+    static int force = -1;
+    if (force < 0) force = tem_env_int("TEM_WINO_EE", 0);
+    BDev best = p;
+    double cbest = 1e300;
+    for (int EE : {9, 17}) {
+      if (force && EE != force) continue;
+      BDev q = p;
+      double c = 1e300;
+      size_t l = 0;
+      const int r = variant == 0 ? plan_bww<8, 8, 2>(q, &l, EE, &c) : variant == 1 ? plan_bww<16, 16, 2>(q, &l, EE, &c)
+                  : variant == 2 ? plan_bww<8, 16, 2>(q, &l, EE, &c) : variant == 3 ? plan_bww<16, 32, 2>(q, &l, EE, &c)
+                  : variant == 4 ? plan_bww<32, 16, 2>(q, &l, EE, &c) : plan_bww<32, 32, 2>(q, &l, EE, &c);
+      if (r == TEM_OK && c < cbest) { best = q; cbest = c; lds_bytes = l; rc = TEM_OK; }
+    }
+    p = best;
+  }
   if (rc != TEM_OK) return rc;
   const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
   if (nblocks > (a->nslab > 0 ? a->nslab : 1024)) return TEM_EUNSUPPORTED;
   if (mode == 1) { *nslab = nblocks; return TEM_OK; }
-  if (mode == 2) { if (name) snprintf(name, name_len, "wino_bww_k<%d, %d, 2, %s>", CI, CO, pair ? "true" : "false"); return TEM_OK; }
+  if (mode == 2) { if (name) snprintf(name, name_len, "wino_bww_k<%d, %d, 2, %s, %d>", CI, CO, pair ? "true" : "false", p.E); return TEM_OK; }
   if (!a->slabs || a->nslab != nblocks || a->accumulate) return TEM_EINVAL;
   p.magicBX = magic_for(p.BX); p.magicE = magic_for(p.E);
   p.slabs = a->slabs; p.slab_stride = a->slab_stride ? a->slab_stride : (int64_t)27 * CI * dy.C;
@@ -467,24 +487,26 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
   if (p.dbg & 8)
     fprintf(stderr, "wino_bww<%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI,
             p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
-  static bool attr[6] = {false, false, false, false, false, false};
+  static bool attr[12] = {};
   auto go = [&](auto kern) -> int {
-    if (!attr[variant]) {
+    const int ai = variant * 2 + (p.E == 17);
+    if (!attr[ai]) {
       hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_B);
       if (e != hipSuccess) return (int)e;
-      attr[variant] = true;
+      attr[ai] = true;
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds_bytes, st, p);
     TEM_CHECK_LAUNCH();
     return TEM_OK;
   };
+  const bool e9 = p.E == 9;
   switch (variant) {
-    case 0: return go(wino_bww_k<8, 8, 2, true>);
-    case 1: return go(wino_bww_k<16, 16, 2, false>);
-    case 2: return go(wino_bww_k<8, 16, 2, false>);
-    case 3: return go(wino_bww_k<16, 32, 2, false>);
-    case 4: return go(wino_bww_k<32, 16, 2, false>);
-    default: return go(wino_bww_k<32, 32, 2, false>);
+    case 0: return e9 ? go(wino_bww_k<8, 8, 2, true, 9>) : go(wino_bww_k<8, 8, 2, true, 17>);
+    case 1: return e9 ? go(wino_bww_k<16, 16, 2, false, 9>) : go(wino_bww_k<16, 16, 2, false, 17>);
+    case 2: return e9 ? go(wino_bww_k<8, 16, 2, false, 9>) : go(wino_bww_k<8, 16, 2, false, 17>);
+    case 3: return e9 ? go(wino_bww_k<16, 32, 2, false, 9>) : go(wino_bww_k<16, 32, 2, false, 17>);
+    case 4: return e9 ? go(wino_bww_k<32, 16, 2, false, 9>) : go(wino_bww_k<32, 16, 2, false, 17>);
+    default: return e9 ? go(wino_bww_k<32, 32, 2, false, 9>) : go(wino_bww_k<32, 32, 2, false, 17>);
   }
 }
 
