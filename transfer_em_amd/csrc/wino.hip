@@ -218,10 +218,6 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
 
   unsigned long long t_last = p.stamps ? clock64() : 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i) do { if (p.stamps) { unsigned long long t_now = clock64(); t_sum[i] += t_now - t_last; t_last = t_now; } } while (0)
-  // Waves 4..7 ("late") share their SIMDs with waves 0..3: they run a step's output transform / epilogue (vector pipe,
-  // stores) at the START of the next step, while their SIMD partner streams MFMAs, and stream their own MFMAs while the
-  // partner runs its epilogue at the END of its step -- the two pipes of a SIMD stay busy across the step boundary.
-  const bool late = (p.dbg & 32) ? wave >= 4 : false;      // measured: no gain (the barriers re-serialise the waves; one wave alone fills 45 % of the matrix pipe); kept for experiments
   f32x4 acc[16];
   f32x4 gv[4];                                             // gate values / keep bytes of the lane's 4 output voxels (2x2 of its tile, its 4
   uint32_t kb[4];                                          //   channels), fetched a step ahead of use
@@ -307,8 +303,6 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     const bool more = step + 1 < nsteps;
     const int sA = (step & 1) ? 2 : 0;                     // ring slots of the step's input planes 0,1 (2,3 are in the other pair)
     STAMP(0);                                              // barrier B / loop overhead
-    if (late && step > 0) finish(oz - 2);
-    STAMP(2);                                              // deferred epilogue (late waves)
     if (EP >= 1) fetch_ep(oz);
 
 #pragma unroll
@@ -328,7 +322,9 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
             v[dy][dx] = *reinterpret_cast<const f32x2 *>(plane + h * p.subb + (2 * dy + (dx & 1)) * rowb + (dx >> 1) * VB + cs[dx >> 1][dy >> 1]);
         if (kz == 1 && h == NH - 1) {
           // every wave is past the step's planes 0 and 1 (wave zb = 0 reads 0,1,2; zb = 1 reads 1,2,3 in this order):
-          // they make room for the next step's, whose DMA flies under the last third of the step and the epilogue
+          // they make room for the next step's.  (hipcc puts vmcnt(0) in front of the next LDS read -- it cannot tell the
+          // ring slots apart -- so the fetch is waited for inside the step; handing the slots over after the step's LAST
+          // reads, with the explicit wait at the step's end, measured 2-4 % slower: less work left to cover the latency.)
           __syncthreads();
           if (more && !(p.dbg & 4)) { dma_plane(izb + 4, sA); dma_plane(izb + 5, sA + 1); }
         }
@@ -358,8 +354,8 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     }
     STAMP(1);                                              // reads + transforms + MFMAs (+ ring hand-over)
 
-    if (!late) finish(oz);
-    STAMP(3);                                              // epilogue (early waves)
+    finish(oz);
+    STAMP(3);                                              // epilogue
     // every wave's DMA of the next step's planes (and, streamed kernels, of the next kernel chunk) has LANDED before the
     // barrier lets anyone read them.  Explicit: until round 3 this held only because hipcc puts vmcnt(0) in front of the first
     // LDS read that follows an LDS-DMA in program order -- which drained the fetch inside the same step by accident of the
@@ -367,7 +363,6 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (late && nsteps > 0) finish(2 * (tz1 - 1) + zb);
   static_assert(!PAIR || EP <= 1, "8 -> 8: forward and gated input-gradient only");
 
   if (p.stamps && lane == 0) {
