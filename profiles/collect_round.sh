@@ -7,9 +7,6 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/round
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# fp32 headline (BASELINE configs[1]) incl. CPU baseline and the sustained window
-python3 $ROOT/bench.py --steps 20 --warmup 5 --kernel-table > $OUT/bench.json 2> $OUT/kernel_table.txt
-echo "bench fp32 done"
 rm -rf $OUT/prof_single $OUT/prof_3streams $OUT/prof_bf16
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_single -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --single-stream > $OUT/bench_single_stream_under_rocprof.json 2> /dev/null
 echo "rocprof single done"
@@ -26,6 +23,11 @@ rm -rf $OUT/pmc_mfma
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sustain 0 --single-stream --no-kernel-profile > /dev/null 2>&1
 python3 $ROOT/profiles/collect_mfma.py $OUT/pmc_mfma $OUT/mfma_busy.json > $OUT/mfma_busy.txt
 echo "pmc done"
+# the counter tables go where bench.py reads them (stamped with the digest of the sources they were collected on), THEN the
+# fp32 headline (BASELINE configs[1]) incl. CPU baseline and the sustained window: its line carries traffic and mfma_busy
+cp $OUT/hbm_traffic.json $OUT/mfma_busy.json $ROOT/profiles/
+python3 $ROOT/bench.py --steps 100 --warmup 20 --kernel-table > $OUT/bench.json 2> $OUT/kernel_table.txt
+echo "bench fp32 done"
 # bf16 mixed precision (BASELINE configs[4], single-GPU share): bench line + kernel table + rocprof stats
 python3 $ROOT/bench.py --dtype bf16 --steps 20 --warmup 5 --kernel-table --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/kernel_table_bf16.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bf16 -- python3 $ROOT/bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --single-stream > $OUT/bench_bf16_single_stream_under_rocprof.json 2> /dev/null
