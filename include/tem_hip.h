@@ -195,6 +195,28 @@ typedef struct tem_reduce_item {
 int tem_reduce_slabs_multi(const tem_reduce_item *items_dev, int32_t nitems, float scale,
                            tem_stream_t stream);
 
+/* The discriminator's 1x1x1 head as one launch per direction (reference discriminator.py:78-99; the launch plans of
+ * models/discriminator.py use it in place of two tem_conv, two tem_conv_bwd_weight, one tem_channel_sum and two
+ * input-gradient launches on the 8^3 logits map):
+ *   forward : p1[v][co] = LeakyReLU_slope(sum_ci e6[v][ci] w1[ci][co]);  z[v] = sum_co p1[v][co] w2[co] + bias[0]
+ *   backward: g_p1 = (p1 > 0 ? 1 : slope_p1) dz w2;  g_e6 = (e6 > 0 ? 1 : slope_e6) (g_p1 . w1^T)   (g_e6 may be NULL
+ *             only with slabs); with slab_w1 != NULL every workgroup b < nslab writes its partial kernel gradients
+ *             slab_w1[b][32*32] (sum_v e6 (x) g_p1), slab_w2[b][32] (sum_v p1 dz), slab_b[b] (sum_v dz) -- rows of the
+ *             layers' ordinary slab sets (tem_reduce_slabs_multi sums them); nslab = tem_disc_head_nslab(nvox).
+ * All tensors dense float32, channels last, 32 channels (the reference hard-codes them, discriminator.py:60,72,78). */
+typedef struct tem_head_bwd_args {
+  const float *dz, *e6, *p1, *w1, *w2;
+  float *g_e6;
+  float slope_p1, slope_e6;
+  float *slab_w1, *slab_w2, *slab_b;
+  int32_t nslab;
+  int64_t nvox;
+} tem_head_bwd_args;
+int tem_disc_head_nslab(int64_t nvox);
+int tem_disc_head_fwd(const float *e6, const float *w1, const float *w2, const float *bias, float *p1, float *z,
+                      int64_t nvox, float slope, tem_stream_t stream);
+int tem_disc_head_bwd(const tem_head_bwd_args *a, tem_stream_t stream);
+
 /* out[c] = (accumulate ? out[c] : 0) + sum over all (n,d,h,w) of g[...,c]   (bias gradient,
  * discriminator.py:97-99) */
 int tem_channel_sum(const tem_view *g, float *out, int32_t accumulate, tem_stream_t stream);

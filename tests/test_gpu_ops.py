@@ -477,3 +477,35 @@ def test_downsample_upsample_blocks_are_callable(H, oracle_lib, is3d):
     keep = ~zero
     pre = oracle_lib.convT_fwd(b, ku[1], st2, (1, 1, 1) if is3d else (0, 1, 1))
     assert rel_err(yt[keep], oracle_lib.leaky_relu(2 * pre)[keep]) < TOL
+
+
+@pytest.mark.parametrize("nvox,need_dw", [(512, True), (512, False), (37, True), (1800, True)])
+def test_discriminator_head_fused(H, oracle_lib, nvox, need_dw):
+    """tem_disc_head_fwd / tem_disc_head_bwd (the 1x1x1 head of discriminator.py:78-99 in one launch per direction)
+    against the oracle's two convolutions, their kernel gradients, the bias gradient and both gated input-gradients."""
+    from transfer_em_amd.models.params import ParamSet
+    rng = np.random.default_rng(nvox)
+    e6 = rnd(rng, 1, 1, 1, nvox, 32)
+    w1, w2, b = rnd(rng, 1, 1, 1, 32, 32) * 0.3, rnd(rng, 1, 1, 1, 32, 1) * 0.3, np.array([0.25], np.float32)
+    p1_ref = oracle_lib.leaky_relu(oracle_lib.conv_fwd(e6, w1, 1, 0))
+    z_ref = oracle_lib.conv_fwd(p1_ref, w2, 1, 0, bias=b)
+    p1, z = torch.empty(1, 1, 1, nvox, 32, device="cuda"), torch.empty(1, 1, 1, nvox, 1, device="cuda")
+    P = ParamSet({"p1": (1, 1, 1, 32, 32), "p2": (1, 1, 1, 32, 1), "p2_bias": (1,)}, "cuda", seed=1)
+    P.load_dict({"p1": w1, "p2": w2, "p2_bias": b})
+    e6d = dev(e6)
+    H.run([H.head_fwd_launch("head", e6d, P.w("p1"), P.w("p2"), P.w("p2_bias"), p1, z)])
+    assert rel_err(p1.cpu().numpy(), p1_ref) < TOL and rel_err(z.cpu().numpy(), z_ref) < TOL
+    dz = rnd(rng, 1, 1, 1, nvox, 1)
+    g_p1 = oracle_lib.leaky_relu_grad_from_out(oracle_lib.conv_bwd_data(dz, w2, p1_ref.shape, 1, 0), p1_ref)
+    g_e6 = oracle_lib.leaky_relu_grad_from_out(oracle_lib.conv_bwd_data(g_p1, w1, e6.shape, 1, 0), e6, np.float32(0.09))
+    ge = torch.full((1, 1, 1, nvox, 32), float("nan"), device="cuda")
+    ws = H.GradWorkspace(P, 1) if need_dw else None
+    l = H.head_bwd_launch("head.bd", dev(dz), e6d, p1, P.w("p1"), P.w("p2"), ge, 0.3, 0.09, ws, 0)
+    H.run([l] + (ws.reduce_launches("r") if need_dw else []))
+    torch.cuda.synchronize()
+    assert rel_err(ge.cpu().numpy(), g_e6) < TOL
+    if need_dw:
+        got = P.to_dict("grad")
+        assert rel_err(got["p1"], oracle_lib.conv_bwd_weight(e6, g_p1, (1, 1, 1), 1, 0)) < TOL
+        assert rel_err(got["p2"], oracle_lib.conv_bwd_weight(p1_ref, dz, (1, 1, 1), 1, 0)) < TOL
+        assert abs(float(got["p2_bias"][0]) - float(dz.astype(np.float64).sum())) < 1e-4 * np.abs(dz).sum()

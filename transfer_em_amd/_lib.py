@@ -66,8 +66,17 @@ class tem_wino_layer(C.Structure):
     _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("ci", C.c_int32), ("co", C.c_int32), ("flip", C.c_int32)]
 
 
+class tem_head_bwd_args(C.Structure):
+    _fields_ = [("dz", C.c_void_p), ("e6", C.c_void_p), ("p1", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p),
+                ("g_e6", C.c_void_p), ("slope_p1", C.c_float), ("slope_e6", C.c_float),
+                ("slab_w1", C.c_void_p), ("slab_w2", C.c_void_p), ("slab_b", C.c_void_p), ("nslab", C.c_int32), ("nvox", C.c_int64)]
+
+
 _VP = C.POINTER(tem_view)
 _SIGS = {
+    "tem_disc_head_nslab": [C.c_int64],
+    "tem_disc_head_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p],
+    "tem_disc_head_bwd": [C.POINTER(tem_head_bwd_args), C.c_void_p],
     "tem_conv": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_transpose": [C.POINTER(tem_conv_args), C.c_void_p],
     "tem_conv_direct": [C.POINTER(tem_conv_args), C.c_void_p],

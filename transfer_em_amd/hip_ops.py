@@ -346,6 +346,36 @@ def bias_grad_launch(name, g, ws, layer, call):
     return launch
 
 
+def head_fwd_launch(name, e6, w1, w2, bias, p1, z, slope=LEAKY):
+    """The discriminator's 1x1x1 head in one launch (tem_disc_head_fwd): p1 = LeakyReLU(e6 . w1), z = p1 . w2 + bias."""
+    lib = _lib.load()
+    for t in (e6, p1, z):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    assert e6.shape[-1] == 32 and p1.shape == e6.shape and z.numel() * 32 == e6.numel()
+    return Launch(lib.tem_disc_head_fwd, (e6.data_ptr(), w1.data_ptr(), w2.data_ptr(), bias.data_ptr(), p1.data_ptr(),
+                                          z.data_ptr(), z.numel(), float(slope)), name, [e6, w1, w2, bias, p1, z],
+                  dict(kernel="head_fwd_k"))
+
+
+def head_bwd_launch(name, dz, e6, p1, w1, w2, g_e6, slope_p1, slope_e6, ws=None, call=0, layers=("p1", "p2", "p2_bias")):
+    """Adjoint of head_fwd_launch (tem_disc_head_bwd): g_e6 and -- with a GradWorkspace -- the kernel-gradient slabs of the
+    two 1x1x1 kernels and the bias (one slab row per workgroup, patched in when the workspace is finalized)."""
+    lib = _lib.load()
+    a = _lib.tem_head_bwd_args()
+    a.dz, a.e6, a.p1, a.w1, a.w2 = dz.data_ptr(), e6.data_ptr(), p1.data_ptr(), w1.data_ptr(), w2.data_ptr()
+    a.g_e6 = g_e6.data_ptr() if g_e6 is not None else None
+    a.slope_p1, a.slope_e6 = float(slope_p1), float(slope_e6)
+    a.nvox = dz.numel()
+    keep = [dz, e6, p1, w1, w2, g_e6, a]
+    if ws is not None:
+        n = lib.tem_disc_head_nslab(a.nvox)
+        a.nslab = n
+        for layer, field in zip(layers, ("slab_w1", "slab_w2", "slab_b")):
+            ws.request(layer, call, n, patch=(lambda ptr, f=field: setattr(a, f, ptr)))
+        keep.append(ws)
+    return Launch(lib.tem_disc_head_bwd, (C.byref(a),), name, keep, dict(kernel="head_bwd_k"))
+
+
 def focal_logits_launch(name, z, target, gamma, losses, slot_mask, loss_scale, dz=None, grad_scale=1.0):
     lib = _lib.load()
     vz = view(z)

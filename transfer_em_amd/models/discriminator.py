@@ -88,12 +88,21 @@ class DiscForward:
         self.prior_fwd = None
         if not bf and refresh_u and P.winograd_launch() is not None:
             L.append(P.winograd_launch("d.winograd"))     # stand-alone plan (see GenForward)
+        # fp32: the two 1x1x1 convolutions of the head are ONE launch (tem_disc_head_fwd; 2 x 20 us of launch latency on
+        # the 8^3 logits map otherwise); bf16 and the direct-form test path keep the generic launches
+        self.fused_head = not bf and not direct
         for name in self.order:
             n = e[name]
             if n < 1:
                 raise RuntimeError(f"input edge {x.shape[3]} is too small for the discriminator")
             A[name] = torch.empty((N, n if is3d else 1, n, n, P.shapes[name][-1]), dtype=x.dtype, device=x.device)
             k, s = _GEOM[name]
+            if self.fused_head and name == "p1":
+                continue
+            if self.fused_head and name == "p2":
+                L.append(H.head_fwd_launch("d.head", A["d3b"], P.w("p1"), P.w("p2"), P.w("p2_bias"), A["p1"], A["p2"]))
+                prev = A[name]
+                continue
             in1 = None
             if name == "d3a" and net.prior is not None:
                 # x2 = disc_prior(inp); x = Concatenate()([x, x2])  (discriminator.py:62-66): the concat is
@@ -139,6 +148,15 @@ class DiscBackward:
             name = order[i]
             k, s = _GEOM[name]
             i3 = is3d if k > 1 else True
+            if fwd.fused_head and name == "p2":
+                # the head's adjoint in one launch: input-gradient down to Downsample_3's output (its double LeakyReLU
+                # gates it) and, with a workspace, the slabs of both 1x1x1 kernels and the bias
+                L.append(H.head_bwd_launch("d.bd.head", dz, A["d3b"], A["p1"], P.w("p1"), P.w("p2"), G["d3b"],
+                                           H.LEAKY, _SLOPE["d3b"], ws if need_dw else None, call))
+                continue
+            if fwd.fused_head and name == "p1":
+                g_out = G["d3b"]
+                continue
             xin = A[order[i - 1]] if i > 0 else fwd.x
             with_prior = name == "d3a" and pf is not None
             if need_dw:
