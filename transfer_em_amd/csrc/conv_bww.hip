@@ -139,31 +139,66 @@ __global__ __launch_bounds__(256) void reduce_slabs_k(const float *slabs, int ns
 }
 
 // One launch finishes the split-K sums of ALL layers of a network: block b reduces items[b]
-// (<= 64 consecutive kernel entries of one layer) over that layer's slabs.  Thread = (entry
-// tid&63, slab lane tid>>6: a wave reads 256 contiguous bytes of a slab); each lane strides the slabs
-// by 4 with 8 loads in flight, then the 4 lanes are summed through LDS in a fixed order (bitwise
-// reproducible).
+// (<= 64 consecutive kernel entries of one layer) over that layer's slabs.  Thread = (entry QUAD tid & 15, slab lane
+// tid >> 4): a lane reads 16 bytes of a slab row, 16 lanes stride the slabs with 8 loads in flight each, then the lanes are
+// summed through LDS in a fixed order (bitwise reproducible).  [Round 2: 4-byte loads, 4 slab lanes -- with the 750 slabs
+// a generator's 32-channel layers collect over three calls a lane walked 24 dependent round trips: 76 us per network
+// and 0.3 ms per step for 170 MB that stream in 35 us.]  Items whose rows are not 16-byte aligned (the bias: one float)
+// take the scalar form.
 __global__ __launch_bounds__(256) void reduce_multi_k(const tem_reduce_item *items, float scale) {
   const tem_reduce_item it = items[blockIdx.x];
+  __shared__ float part[16][64];
+  const bool vec = (it.count & 3) == 0 && (it.stride & 3) == 0 && (((uintptr_t)it.slabs) & 15) == 0;
+  if (vec) {
+    const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    float4 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * q < it.count) {
+      const float *p = it.slabs + 4 * q;
+      int s = sl;
+      for (; s + 112 < it.nslab; s += 128) {                 // 8 loads in flight per lane
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float4 v = *reinterpret_cast<const float4 *>(p + (int64_t)(s + 16 * k) * it.stride);
+          a[k].x += v.x; a[k].y += v.y; a[k].z += v.z; a[k].w += v.w;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (s + 16 * k < it.nslab) {
+          const float4 v = *reinterpret_cast<const float4 *>(p + (int64_t)(s + 16 * k) * it.stride);
+          a[k].x += v.x; a[k].y += v.y; a[k].z += v.z; a[k].w += v.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 4; k > 0; k >>= 1)
+#pragma unroll
+      for (int j = 0; j < k; ++j) { a[j].x += a[j + k].x; a[j].y += a[j + k].y; a[j].z += a[j + k].z; a[j].w += a[j + k].w; }
+    *reinterpret_cast<float4 *>(&part[sl][4 * q]) = a[0];
+    __syncthreads();
+    if (threadIdx.x < it.count) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
+      it.out[threadIdx.x] = v * scale;
+    }
+    return;
+  }
   const int pi = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (pi < it.count) {
     const float *p = it.slabs + pi;
     int s = sl;
-    for (; s + 28 < it.nslab; s += 32) {                   // 8 loads in flight per lane (the sums are latency-bound)
+    for (; s + 12 < it.nslab; s += 16) {
       s0 += p[(int64_t)s * it.stride];
       s1 += p[(int64_t)(s + 4) * it.stride];
       s2 += p[(int64_t)(s + 8) * it.stride];
       s3 += p[(int64_t)(s + 12) * it.stride];
-      s4 += p[(int64_t)(s + 16) * it.stride];
-      s5 += p[(int64_t)(s + 20) * it.stride];
-      s6 += p[(int64_t)(s + 24) * it.stride];
-      s7 += p[(int64_t)(s + 28) * it.stride];
     }
     for (; s < it.nslab; s += 4) s0 += p[(int64_t)s * it.stride];
   }
-  s0 += s4; s1 += s5; s2 += s6; s3 += s7;
-  __shared__ float part[4][64];
   part[sl][pi] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (sl == 0 && pi < it.count) {
