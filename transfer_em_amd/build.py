@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libtem_hip.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 SOURCES = ["conv_direct.hip", "conv_bww.hip", "bww_lds.hip", "conv_lds.hip", "elementwise.hip", "dispatch.hip",
-           "stencil_c1.hip", "convT_mfma.hip", "datapipe.hip", "conv_bf16.hip", "convT_bf16.hip", "bww_bf16.hip", "elementwise_bf16.hip", "wino.hip", "wino_bww.hip", "bww_c1.hip", "conv_s2.hip", "c1out_mfma.hip", "bww_s2.hip", "head.hip"]
+           "stencil_c1.hip", "convT_mfma.hip", "datapipe.hip", "conv_bf16.hip", "conv3_bf16.hip", "convT_bf16.hip", "bww_bf16.hip", "elementwise_bf16.hip", "wino.hip", "wino_bww.hip", "bww_c1.hip", "conv_s2.hip", "c1out_mfma.hip", "bww_s2.hip", "head.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-pass-failed"] + os.environ.get("TEM_BUILD_FLAGS", "").split()
 # TEM_BUILD_FLAGS=-DTEM_DEBUG_KNOBS: the environment knobs of csrc/tem_common.h (microbenchmarks only; off in the shipped build)

@@ -501,16 +501,22 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
 
 }  // namespace conv_bf16
 
+namespace conv3_bf16 { int dispatch(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int name_len); }
+
 // bf16 mode: activations, gate / add views and the packed kernel are bf16 (the float* fields of tem_conv_args carry
 // bf16 pointers, strides in elements); slope / bias / dropout as in tem_conv.
 extern "C" int tem_conv_bf16(const tem_conv_args *a, tem_stream_t stream) {
   TEM_CLEAR_ERR();
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->out0) || !a->w) return TEM_EINVAL;
+  const int rc = conv3_bf16::dispatch(a, (hipStream_t)stream, false, nullptr, 0);     // 3x3x3 stride 1, 8..32 channels
+  if (rc != TEM_EUNSUPPORTED) return rc;
   return conv_bf16::dispatch(a, (hipStream_t)stream, false);
 }
 
 extern "C" int tem_conv_bf16_describe(const tem_conv_args *a, char *buf, int32_t len) {
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->out0) || !a->w) return TEM_EINVAL;
+  const int rc3 = conv3_bf16::dispatch(a, nullptr, true, buf, len);
+  if (rc3 != TEM_EUNSUPPORTED) return rc3;
   conv_bf16::g_name = buf; conv_bf16::g_name_len = len;
   int rc = conv_bf16::dispatch(a, nullptr, true);
   conv_bf16::g_name = nullptr;
