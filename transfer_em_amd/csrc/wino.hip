@@ -147,9 +147,9 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     for (int h = 0; h < NH; ++h) {
       char *const dst = ring + slot * p.slotb + h * p.subb;
       if (!two_in || 8 * h < p.C0)
-        dma_subimage<NI>(in0n + izc * p.i0D + 8 * h, zok ? p.span0 - 32 * h : 0, voff0, dst, wave, p.ndma);
+        dma_subimage<NI, !STREAM>(in0n + izc * p.i0D + 8 * h, zok ? p.span0 - 32 * h : 0, voff0, dst, wave, p.ndma);
       else
-        dma_subimage<NI>(in1n + izc * p.i1D + (8 * h - p.C0), zok ? p.span1 - 4 * (8 * h - p.C0) : 0, voff1, dst, wave, p.ndma);
+        dma_subimage<NI, !STREAM>(in1n + izc * p.i1D + (8 * h - p.C0), zok ? p.span1 - 4 * (8 * h - p.C0) : 0, voff1, dst, wave, p.ndma);
     }
   };
 
@@ -176,6 +176,7 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
     float4 *ud = reinterpret_cast<float4 *>(uld);
     for (int i = tid; i < UF4; i += 512) ud[i] = us[i];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prologue's planes (inline-assembly DMA: no wait of the compiler's)
   __syncthreads();
 
   constexpr int rowb = EE * VB;                              // bytes per (yr, o) row of a sub-image

@@ -117,9 +117,9 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
     for (int h = 0; h < NH; ++h) {
       char *const dst = ring + slot * p.slotb + h * p.subb;
       if (!two_in || 8 * h < p.C0)
-        dma_subimage<NI>(in0n + izc * p.i0D + 8 * h, zok ? p.span0 - 32 * h : 0, voff0, dst, wave, p.ndma);
+        dma_subimage<NI, (CI <= 16)>(in0n + izc * p.i0D + 8 * h, zok ? p.span0 - 32 * h : 0, voff0, dst, wave, p.ndma);
       else
-        dma_subimage<NI>(in1n + izc * p.i1D + (8 * h - p.C0), zok ? p.span1 - 4 * (8 * h - p.C0) : 0, voff1, dst, wave, p.ndma);
+        dma_subimage<NI, (CI <= 16)>(in1n + izc * p.i1D + (8 * h - p.C0), zok ? p.span1 - 4 * (8 * h - p.C0) : 0, voff1, dst, wave, p.ndma);
     }
   };
   const int izb0 = 2 * tz0 - p.P;
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
           else g[j][o4].x = v;
         }
   };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prologue's planes (inline-assembly DMA for C_in <= 16, wino_common.h; at 32 it measured 7-10 % slower)
   __syncthreads();
 
   // The point half ph is wave-uniform; the loop body is compiled once per value (static row indices: no selects).

@@ -46,14 +46,31 @@ __device__ __forceinline__ int swz(int e, int yr) { return ((e >> 3) + ((yr >> 1
 
 // One 8-channel sub-image of one input plane: wave-instruction j = wave + 8 i moves chunk slots 64 j .. 64 j + 63 (1 KB,
 // lane-linear) from the plane at `base`; offsets outside [0, span) arrive as zeros.
-template <int NI>
+// ASM: the fetch is issued as inline assembly.  For the builtin, hipcc cannot tell the ring slots apart and puts
+// s_waitcnt vmcnt(0) in front of the first LDS read that follows it in program order -- the fetch latency inside the step,
+// on every wave; with ASM the kernel's own waits (before the barrier that hands the slots over) are the only ones, and they
+// MUST be there: the compiler no longer knows that anything is in flight.
+template <int NI, bool ASM = false>
 __device__ __forceinline__ void dma_subimage(const float *base, int span, const int *voff, char *dst, int wave, int ndma) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, span, 0x00020000);
+  if constexpr (ASM) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t r = u32x4_t{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)base),
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)((uintptr_t)base >> 32) & 0xffffu)), (uint32_t)span, 0x00020000u};
+    const uint32_t d0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)dst;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int j = wave + 8 * i;
-    if (j < ndma)                                            // wave-uniform
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, voff[i], 0, 0, 0);
+    for (int i = 0; i < NI; ++i) {
+      const int j = wave + 8 * i;
+      if (j < ndma)                                          // wave-uniform
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(d0 + j * 1024), "v"(voff[i]), "s"(r) : "memory");
+    }
+  } else {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, span, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int j = wave + 8 * i;
+      if (j < ndma)                                          // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, voff[i], 0, 0, 0);
+    }
   }
 }
 
