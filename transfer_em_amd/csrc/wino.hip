@@ -35,6 +35,15 @@
 
 namespace wino {
 
+// device-side diagnostics (phase stamps, ablation flags) exist only in -DTEM_DEBUG_KNOBS builds: in the shipped kernels they
+// cost registers (18 VGPRs of stamp sums) and scalar branches inside the step loop
+#ifdef TEM_DEBUG_KNOBS
+#define KDBG(x) (x)
+#else
+#define KDBG(x) 0
+#endif
+
+
 struct Ep32 {
   float slope;
   const float *gate; int32_t gN, gD, gH, gW; float gate_slope;
@@ -217,8 +226,12 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) cs[a][b] = ((q >> 1) ^ swz(txA + a, 2 * (tyA + b))) * 16;
 
+#ifdef TEM_DEBUG_KNOBS
   unsigned long long t_last = p.stamps ? clock64() : 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i) do { if (p.stamps) { unsigned long long t_now = clock64(); t_sum[i] += t_now - t_last; t_last = t_now; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
   f32x4 acc[16];
   f32x4 gv[4];                                             // gate values / keep bytes of the lane's 4 output voxels (2x2 of its tile, its 4
   uint32_t kb[4];                                          //   channels), fetched a step ahead of use
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
           // ring slots apart -- so the fetch is waited for inside the step; handing the slots over after the step's LAST
           // reads, with the explicit wait at the step's end, measured 2-4 % slower: less work left to cover the latency.)
           __syncthreads();
-          if (more && !(p.dbg & 4)) { dma_plane(izb + 4, sA); dma_plane(izb + 5, sA + 1); }
+          if (more && !(KDBG(p.dbg & 4))) { dma_plane(izb + 4, sA); dma_plane(izb + 5, sA + 1); }
         }
         // input transform B^T d B on (y, x), both channels of the pair at once
 #pragma unroll
@@ -366,9 +379,11 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   }
   static_assert(!PAIR || EP <= 1, "8 -> 8: forward and gated input-gradient only");
 
+#ifdef TEM_DEBUG_KNOBS
   if (p.stamps && lane == 0) {
     for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = t_sum[i];
   }
+#endif
 #undef STAMP
 }
 
@@ -528,7 +543,7 @@ int run_best(Dev p, hipStream_t st, bool dry) {
     return TEM_OK;
   }
   const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
-  if (p.dbg & 8)
+  if (KDBG(p.dbg & 8))
     fprintf(stderr, "wino<%d,%d,%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI, CO, EP,
             p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
   return p.E == 9 ? launch<CI, CO, NI, EP, 9>(p, lds_bytes, st) : launch<CI, CO, NI, EP, 17>(p, lds_bytes, st);

@@ -31,6 +31,15 @@
 
 namespace wino {
 
+// device-side diagnostics (phase stamps, ablation flags) exist only in -DTEM_DEBUG_KNOBS builds: in the shipped kernels they
+// cost registers (18 VGPRs of stamp sums) and scalar branches inside the step loop
+#ifdef TEM_DEBUG_KNOBS
+#define KDBG(x) (x)
+#else
+#define KDBG(x) 0
+#endif
+
+
 struct BDev {
   const float *in0, *in1;
   int32_t i0N, i0D, i0H, i0W, i1N, i1D, i1H, i1W;
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
   const int bx = seg % p.nbx; seg /= p.nbx;
   const int by = seg % p.nby;
   const int n = seg / p.nby;
-  const int tz0 = zseg * p.zper, tz1 = min(p.NTZ, tz0 + p.zper), nsteps = (p.dbg & 128) ? 0 : tz1 - tz0;
+  const int tz0 = zseg * p.zper, tz1 = min(p.NTZ, tz0 + p.zper), nsteps = (KDBG(p.dbg & 128)) ? 0 : tz1 - tz0;
   const int oy0 = by * 2 * p.BY, ox0 = bx * 2 * p.BX;
   const int ntile = p.BY * p.BX;
 
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
           // every wave is past the step's planes 0 and 1 (zo = 1 starts at plane 1 = its tap 0): they make room for
           // the next step's planes 2, 3
           __syncthreads();
-          if (more && !(p.dbg & 4)) { dma_plane(izb + 4, sA); dma_plane(izb + 5, sA + 1); }
+          if (more && !(KDBG(p.dbg & 4))) { dma_plane(izb + 4, sA); dma_plane(izb + 5, sA + 1); }
         }
         // B^T on y for point rows 2 PH, 2 PH + 1, then on x
         f32x2 vp[2][4];
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(512) void wino_bww_k(BDev p) {
     }
     const int ci0 = CI >= 16 ? 16 * (c % CIH) : 0, co0 = 16 * (c / CIH);
     constexpr int CIB = CI >= 16 ? 16 : CI;
-    if (!(p.dbg & 256)) {
+    if (!(KDBG(p.dbg & 256))) {
       for (int id = tid; id < 3 * CIB * COB; id += 512) {    // (kz, ci, co) of the combination's block
         const int co = id % COB, ci = (id / COB) % CIB, kz = id / (COB * CIB);
         float du[4][4];
@@ -485,7 +494,7 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
     if (dbg < 0) dbg = tem_env_int("TEM_DEBUG_FLAGS", 0);
     p.dbg = dbg;
   }
-  if (p.dbg & 8)
+  if (KDBG(p.dbg & 8))
     fprintf(stderr, "wino_bww<%d> O=%dx%dx%d: BY=%d BX=%d nby=%d nbx=%d zsegs=%d zper=%d blocks=%d lds=%zu\n", CI,
             p.OD, p.OH, p.OW, p.BY, p.BX, p.nby, p.nbx, p.zsegs, p.zper, nblocks, lds_bytes);
   static bool attr[12] = {};
