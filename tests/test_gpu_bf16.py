@@ -242,7 +242,21 @@ def test_kernel_gradient_bf16(H, oracle_lib, CI, CO, k, s, pad, n):
     g = rb(rnd(rng, 2, o[0], o[1], o[2], CO))
     ref = oracle_lib.conv_bwd_weight(x, g, (k, k, k), s, pad)
     got, kern = _bww(H, devb(x), devb(g), ref.shape, k, s, pad)
-    assert kern.startswith("bww_bf16_k"), kern
+    assert kern.startswith(("bww_bf16_k", "bww_c1m_h_k")), kern
+    assert rel_err(got, ref) < 2e-5, kern
+
+
+@pytest.mark.parametrize("CO,pad,dims", [(8, 0, (11, 21, 38)), (16, 0, (9, 14, 36)), (8, 2, (7, 9, 18)), (16, 2, (10, 13, 22))])
+def test_kernel_gradient_bf16_one_input_channel(H, oracle_lib, CO, pad, dims):
+    """bww_c1m_h_k: the one-input-channel kernel gradient on the matrix cores with bf16 X / G (4-byte LDS-DMA of the X rows,
+    16-byte of G; padding = zeros outside X, as the swapped form of the C_out = 1 layers needs), ragged batch-2 volumes."""
+    rng = np.random.default_rng(CO + pad)
+    x = rb(rnd(rng, 2, *dims, 1))
+    o = [d + 2 * pad - 2 for d in dims]
+    g = rb(rnd(rng, 2, o[0], o[1], o[2], CO))
+    ref = oracle_lib.conv_bwd_weight(x, g, (3, 3, 3), 1, pad)
+    got, kern = _bww(H, devb(x), devb(g), ref.shape, 3, 1, pad)
+    assert kern.startswith("bww_c1m_h_k"), kern
     assert rel_err(got, ref) < 2e-5, kern
 
 

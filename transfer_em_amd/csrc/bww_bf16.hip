@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+int tem_bww_c1_bf16_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out, char *name, int name_len);
+
 namespace bww_bf16 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -265,6 +267,10 @@ int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
 
 int dispatch(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out) {
   const tem_view &i0 = a->in0, &g = a->dout;
+  {                                                          // one input channel, 3x3x3: the matrix-core march of bww_c1.hip
+    const int rc = tem_bww_c1_bf16_try(a, st, dry, nslab_out, g_name, g_name_len);
+    if (rc != TEM_EUNSUPPORTED) return rc;
+  }
   if (!(a->kd == a->kh && a->kh == a->kw && a->sd == a->sh && a->sh == a->sw && a->pd == a->ph && a->ph == a->pw))
     return TEM_EUNSUPPORTED;
   if (g.N != i0.N) return TEM_ESHAPE;

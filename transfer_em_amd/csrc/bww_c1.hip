@@ -399,6 +399,189 @@ static int run(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out, 
   return TEM_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------ bf16 inputs (config 5)
+// The same march with bf16 X and G (2-byte elements, strides in elements), fp32 MFMAs and fp32 slabs: the shape-generic
+// bww_bf16_k spent 59 us on the first layer's kernel gradient (2-byte gathers of the one-channel input per MFMA operand of
+// a K = voxels product), 0.6 ms of the bf16 step.  Differences to bww_c1m_k: a G chunk (16 bytes) is 8 elements -- one
+// voxel of 8 channels, half a voxel of 16 --, the wave's X rows arrive as ONE 4-byte LDS-DMA on 48 lanes (2 voxels per
+// lane: W even, the chunk grid aligned to even x, so no chunk crosses a row end; 16-byte chunks would, at W = 132 / 98),
+// and a fragment element is a 2-byte LDS read shifted into the upper half of the register (bf16 -> fp32 is exact).
+template <int CO>
+__global__ __launch_bounds__(256) void bww_c1m_h_k(C1Dev p) {
+  typedef unsigned short u16;
+  constexpr int NZ = CO == 8 ? 2 : 1, MT = CO == 8 ? 3 : 2, PY = 8, PX = 16, Q = 3;
+  constexpr int XP = 24, XPL = 160;                           // X rows of a wave: row pitch, plane pitch (elements; 320 bytes = 64 mod 256)
+  constexpr int GROW = PX * CO, GPL = 2 * GROW + 32;          // G rows of a wave: elements per row, per plane slot (+64 bytes between the planes of a pair)
+  constexpr int RG = NZ * Q, RX = NZ * Q + 2;
+  constexpr int NCH = 2 * GROW / 8;                           // 16-byte chunks of the wave's two G rows: 32 (C_out 8) or 64
+  constexpr int ND = 2 * NZ;                                  // DMA instructions per step: one per G plane, one per new X plane
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int wlds = RG * GPL + RX * XPL;                   // elements of LDS per wave
+  u16 *const gs = reinterpret_cast<u16 *>(smem) + wave * wlds;
+  u16 *const xs = gs + RG * GPL;
+  const int m = lane & 15, kq = lane >> 4;
+  int b = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int zseg = b % p.zsegs; b /= p.zsegs;
+  const int bx = b % p.nxb; b /= p.nxb;
+  const int by = b % p.nyb;
+  const int n = b / p.nyb;
+  const int z0 = zseg * p.zper, z1 = min(p.OD, z0 + p.zper), nz = z1 - z0;
+  const int nsteps = (nz + NZ - 1) / NZ;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int OOB = (int)0x80000000;
+  const u16 *const gp_ = reinterpret_cast<const u16 *>(p.g), *const xp_ = reinterpret_cast<const u16 *>(p.x);
+
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)(gp_ + (size_t)n * p.gN), 0, p.gspan, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(xp_ + (size_t)n * p.xN), 0, p.xspan, 0x00020000);
+  int goff = OOB;                                             // byte offset of the lane's chunk inside a plane of G
+  if (lane < NCH) {
+    const int r = lane / (GROW / 8), f = (lane % (GROW / 8)) * 8;
+    const int oy = by * PY + 2 * wave + r, ox = bx * PX + f / CO;
+    if (oy < p.OH && ox < p.OW) goff = (oy * p.gH + ox * p.gW + f % CO) * 2;
+  }
+  auto dma_g = [&](int gpl) {                                 // plane z0 + gpl of G -> slot gpl % RG (zeros past the run)
+    const int off = (gpl < nz && goff != OOB) ? goff + (z0 + gpl) * p.gD * 2 : OOB;
+    if (lane < NCH)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (__attribute__((address_space(3))) void *)(gs + (gpl % RG) * GPL), 16, off, 0, 0, 0);
+  };
+  const int xsh = p.P <= 0 ? (-p.P / 2) * 2 : -((p.P + 1) / 2) * 2;      // floor(-P / 2) * 2
+  const int sh = -p.P - xsh;                                   // 0 or 1: column of the voxel that output x = 0 reads with tap dx = 0
+  int xoffg = OOB;
+  if (lane < 48) {
+    const int yy = lane / 12, c12 = lane - yy * 12;
+    const int iy = by * PY + 2 * wave - p.P + yy, ix = bx * PX + xsh + 2 * c12;
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) xoffg = (iy * p.xH + ix) * 2;
+  }
+  auto dma_x = [&](int xpl) {                                 // plane z0 - P + xpl of X -> slot xpl % RX
+    const int iz = z0 - p.P + xpl;
+    const int off = ((unsigned)iz < (unsigned)p.D && xoffg != OOB) ? xoffg + iz * p.xD * 2 : OOB;
+    if (lane < 48)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(xs + (xpl % RX) * XPL), 4, off, 0, 0, 0);
+  };
+  auto dma_step = [&](int s) {
+#pragma unroll
+    for (int h = 0; h < NZ; ++h) dma_g(NZ * s + h);
+#pragma unroll
+    for (int h = 0; h < NZ; ++h) dma_x(NZ * s + 2 + h);
+  };
+  dma_x(0); dma_x(1);
+#pragma unroll
+  for (int s = 0; s < Q - 1; ++s) dma_step(s);
+
+  int aconst[MT], azi[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int R = 16 * t + m;
+    if (R >= (NZ + 2) * 9) R = 0;
+    const int zi = R / 9, dy = (R - zi * 9) / 3, dx = R - zi * 9 - dy * 3;
+    azi[t] = zi;
+    aconst[t] = dy * XP + dx + kq + sh;
+  }
+  const int h = CO == 8 ? (m >> 3) : 0;
+  const int bconst = (kq * CO + (CO == 8 ? (m & 7) : m)) + h * GPL;
+  auto up = [](u16 v) { return __uint_as_float((uint32_t)v << 16); };
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND * (Q - 2)) : "memory");      // this wave's fetches for step s have landed
+    dma_step(s + Q - 1);
+    const int sx = (NZ * s) % RX;
+    const u16 *xa[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      int sl = sx + azi[t];
+      sl = sl >= RX ? sl - RX : sl;
+      xa[t] = xs + sl * XPL + aconst[t];
+    }
+    const u16 *gb = gs + (NZ * (s % Q)) * GPL + bconst;
+    float af[8][MT], bf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int rr = ks >> 2, j = ks & 3;
+      bf[ks] = up(gb[rr * GROW + 4 * j * CO]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) af[ks][t] = up(xa[t][rr * XP + 4 * j]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks][t], bf[ks], acc[t], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float *red = smem;                                          // [4][MT * 16][16]
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * MT * 16 + 16 * t + 4 * kq + r) * 16 + m] = acc[t][r];
+  __syncthreads();
+  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride;
+  for (int i = tid; i < 27 * CO; i += 256) {
+    const int tap = i / CO, co = i - tap * CO;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float *rw = red + w * MT * 16 * 16;
+      if (CO == 16) v += rw[tap * 16 + co];
+      else v += rw[tap * 16 + co] + rw[(tap + 9) * 16 + 8 + co];
+    }
+    slab[i] = v;
+  }
+}
+
+static int run_h(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out, char *name, int name_len) {
+  const tem_view &x = a->in0, &g = a->dout;                   // bf16 tensors behind the float* fields, strides in elements
+  const bool cube = a->kd == 3 && a->kh == 3 && a->kw == 3 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->pd == a->ph &&
+                    a->ph == a->pw && a->pd >= 0;
+  if (!cube || x.C != 1 || a->in1.ptr || (g.C != 8 && g.C != 16) || x.D < 2 || x.N != g.N) return TEM_EUNSUPPORTED;
+  // X rows arrive as 4-byte chunks of 2 voxels: even W, even strides and a 4-byte aligned origin
+  if (x.sW != 1 || x.W % 2 || x.sH % 2 || x.sD % 2 || x.sN % 2 || ((uintptr_t)x.ptr & 3)) return TEM_EUNSUPPORTED;
+  auto span = [](const tem_view &v) {
+    return (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH + (int64_t)(v.W - 1) * v.sW + v.C;
+  };
+  if (span(x) >= ((int64_t)1 << 30) || span(g) >= ((int64_t)1 << 30)) return TEM_EUNSUPPORTED;
+  if (((uintptr_t)g.ptr & 15) || g.sW % 8 || g.sH % 8 || g.sD % 8 || g.sN % 8) return TEM_EUNSUPPORTED;
+  const int CO = g.C, PY = 8;
+  C1Dev p{};
+  p.x = x.ptr; p.xN = (int)x.sN; p.xD = (int)x.sD; p.xH = (int)x.sH; p.xW = (int)x.sW;
+  p.D = x.D; p.H = x.H; p.W = x.W;
+  p.g = g.ptr; p.gN = (int)g.sN; p.gD = (int)g.sD; p.gH = (int)g.sH; p.gW = (int)g.sW;
+  p.OD = g.D; p.OH = g.H; p.OW = g.W;
+  p.P = a->pd;
+  p.nyb = (g.H + PY - 1) / PY; p.nxb = (g.W + 15) / 16;
+  const int cols = g.N * p.nyb * p.nxb;
+  const int cap = a->nslab > 0 ? a->nslab : 1024;
+  if (cols > cap) return TEM_EUNSUPPORTED;
+  int zsegs = std::max(1, std::min((1536 + cols / 2) / cols, std::max(1, g.D / 8)));
+  int zper = (g.D + zsegs - 1) / zsegs;
+  if (CO == 8) zper += zper & 1;
+  if ((int64_t)cols * ((g.D + zper - 1) / zper) > cap) return TEM_EUNSUPPORTED;
+  zsegs = (g.D + zper - 1) / zper;
+  p.zsegs = zsegs; p.zper = zper;
+  const int nblocks = cols * zsegs;
+  const int NZ = CO == 8 ? 2 : 1, MT = CO == 8 ? 3 : 2, Q = 3;
+  const size_t lds = std::max<size_t>((size_t)4 * ((size_t)NZ * Q * (2 * 16 * CO + 32) + (size_t)(NZ * Q + 2) * 160) * 2, (size_t)4 * MT * 16 * 16 * 4);
+  const int64_t gspan = ((int64_t)(g.D - 1) * g.sD + (int64_t)(g.H - 1) * g.sH + (int64_t)(g.W - 1) * g.sW + g.C) * 2;
+  p.gspan = (int)gspan;
+  p.xspan = (int)(((int64_t)(x.D - 1) * x.sD + (int64_t)(x.H - 1) * x.sH + (int64_t)(x.W - 1) * x.sW + 1) * 2);
+  if (nslab_out) *nslab_out = nblocks;
+  if (name) snprintf(name, name_len, "bww_c1m_h_k<%d>", CO);
+  if (dry) return TEM_OK;
+  if (!a->slabs || a->nslab != nblocks || a->accumulate) return TEM_EINVAL;
+  p.slabs = a->slabs; p.slab_stride = a->slab_stride ? a->slab_stride : (int64_t)27 * CO;
+  if (CO == 8) hipLaunchKernelGGL(bww_c1m_h_k<8>, dim3(nblocks), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(bww_c1m_h_k<16>, dim3(nblocks), dim3(256), lds, st, p);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
 }  // namespace bwwc1
 
 // Same contract as tem_bww_lds_try (conv_bww.hip): dry = only report support and the slab count.
@@ -407,3 +590,8 @@ int tem_bww_c1_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_o
 }
 
 int tem_bww_c1_describe(const tem_bww_args *a, char *buf, int len) { return bwwc1::run(a, nullptr, true, nullptr, buf, len); }
+
+// bf16 inputs (bww_bf16.hip dispatches here first for the one-channel layers)
+int tem_bww_c1_bf16_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out, char *name, int name_len) {
+  return bwwc1::run_h(a, st, dry, nslab_out, name, name_len);
+}
