@@ -65,6 +65,32 @@ def test_conv_bf16_forward(H, oracle_lib, CI, CO, k, s, pad, n):
     assert rel_err(out.float().cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize("CO", [8, 16])
+def test_conv_bf16_one_input_channel(H, oracle_lib, CO):
+    """c1_mfma_h_k: the one-input-channel 3x3x3 layers with bf16 tensors (fp32 LDS patch widened by the loader, fp32 MFMAs,
+    8-byte bf16 stores): forward with LeakyReLU, and the input-gradient form (flipped taps, padding 2, gate), batch 2."""
+    rng = np.random.default_rng(CO)
+    x = rb(rnd(rng, 2, 9, 19, 36, 1))
+    w = rb(rnd(rng, 3, 3, 3, 1, CO) * 0.3)
+    ref = oracle_lib.leaky_relu(oracle_lib.conv_fwd(x, w, 1, 0, None))
+    out = torch.empty(ref.shape, dtype=torch.bfloat16, device="cuda")
+    launch = H.conv_launch("t", devb(x), pack(w), out, 3, 1, 0, slope=0.3)
+    H.run([launch])
+    assert launch.meta["kernel"].startswith("c1_mfma_h_k"), launch.meta["kernel"]
+    assert rel_err(out.float().cpu().numpy(), ref) < TOL
+    # input-gradient of a CO -> 1 forward layer: operator 1 -> CO with the forward kernel (tap, CO, 1), gate = the saved input
+    g = rb(rnd(rng, 2, 7, 10, 20, 1))
+    wf = rb(rnd(rng, 3, 3, 3, CO, 1) * 0.3)
+    shape = (2, 9, 12, 22, CO)
+    saved = rb(rnd(rng, *shape))
+    ref = oracle_lib.leaky_relu_grad_from_out(oracle_lib.conv_bwd_data(g, wf, shape), saved)
+    out = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+    launch = H.conv_launch("t", devb(g), devb(wf.reshape(-1)), out, 3, 1, 2, layout=H.TEM_W_FLIP_CO_CI, gate=devb(saved))
+    H.run([launch])
+    assert launch.meta["kernel"].startswith("c1_mfma_h_k"), launch.meta["kernel"]
+    assert rel_err(out.float().cpu().numpy(), ref) < TOL
+
+
 @pytest.mark.parametrize("CI,CO", [(8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16), (32, 32)])
 def test_conv3_bf16_marching_kernel(H, oracle_lib, CI, CO):
     """conv3_bf16_k (z-marching 3x3x3 kernel, LDS-DMA ring with permuted channel chunks): forward on a ragged non-cubic

@@ -550,6 +550,234 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   return TEM_EUNSUPPORTED;
 }
 
+
+// ------------------------------------------------------------------------------------------ bf16 in / out (config 5)
+// c1_mfma_k with bf16 tensors (the shape-generic conv_bf16_k took 30 us for g.c0 and 23 us for the input-gradient of g.f2:
+// the 27 taps of a one-channel input are ONE k-step of the bf16 MFMA, so its per-tile index work is all there is).  The LDS
+// patch stays fp32 -- the loader widens its 8-byte chunks of 4 voxels once (bf16 -> fp32 is a shift) -- so the fragment reads
+// and the fp32 MFMA chain are c1_mfma_k's; the kernel copy (packed bf16 [tap][co]) is widened into the B registers, the gate
+// arrives as 8 bytes per lane and the lane's 4 channels leave as an 8-byte bf16 store.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+
+template <int CO, bool FLIP, int EPI>
+__global__ __launch_bounds__(256) void c1_mfma_h_k(DevM p, const unsigned short *__restrict__ wgt) {
+  typedef unsigned short u16;
+  constexpr int NZ = CO == 8 ? 2 : 1, NP = NZ + 2, NR = (NP * 3 + 3) / 4, KS = NR * 3, NCH = 2;
+  constexpr int OOB = (int)0x80000000;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+  const int rows = p.TY + 2;
+  const int plane = rows * p.colsP;
+  int b = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int zg = b % p.nzg; b /= p.nzg;
+  const int typ = b % p.nty;
+  const int n = b / p.nty;
+  const int oy0 = typ * p.TY, oz0 = zg * NZ;
+  auto up = [](uint32_t h) { return __uint_as_float(h << 16); };
+
+  float B[KS];
+  int rowoff[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int r = 4 * j + kq;
+    const bool real = r < NP * 3;
+    const int zi = real ? r / 3 : 0, dy = real ? r - zi * 3 : 0;
+    rowoff[j] = (zi * plane + dy * p.colsP + m + p.sh) * 4;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      float v = 0.f;
+      if (real) {
+        const int zo = CO == 8 ? (m >> 3) : 0, dz = zi - zo;
+        if (dz >= 0 && dz <= 2) {
+          const int tap = dz * 9 + dy * 3 + dx;
+          v = up(wgt[(FLIP ? 26 - tap : tap) * CO + (CO == 8 ? (m & 7) : m)]);
+        }
+      }
+      B[3 * j + dx] = v;
+    }
+  }
+  {
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
+    const int nchunk = rows * p.cpr;
+    u32x2 pf[NP][NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * 256;
+      const int r = (int)__umulhi((uint32_t)id, p.magicCpr), c4 = id - r * p.cpr;
+      const int iy = oy0 - p.P + r;
+      const int ix0 = p.xs + 4 * c4;
+      const bool okxy = id < nchunk && (unsigned)iy < (unsigned)p.H && (unsigned)ix0 < (unsigned)p.W;
+      const int base = (n * p.iN + iy * p.iH + ix0) * 2;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        const int iz = oz0 - p.P + pl;
+        const int off = (okxy && (unsigned)iz < (unsigned)p.D) ? base + iz * p.iD * 2 : OOB;
+        pf[pl][i] = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * 256;
+      if (id < nchunk) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          const u32x2 v = pf[pl][i];
+          *reinterpret_cast<u32x4 *>(lds + pl * plane + id * 4) = u32x4{v.x << 16, v.x & 0xffff0000u, v.y << 16, v.y & 0xffff0000u};
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int zo = CO == 8 ? (kq >> 1) : 0, co0 = CO == 8 ? 4 * (kq & 1) : 4 * kq;
+  const int oz = oz0 + zo;
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)((u16 *)p.out + (size_t)n * p.oN), 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)((const u16 *)p.gate + (size_t)n * p.gN), 0, EPI == 1 ? p.gate_bytes : 0, 0x00020000);
+  const bool zok = oz < p.OD;
+  const int obase = (oz * p.oD + oy0 * p.oH + m * p.oW + co0) * 2;
+  const int gbase = EPI == 1 ? (oz * p.gD + oy0 * p.gH + m * p.gW + co0) * 2 : 0;
+  const int ntiles = p.TXT * p.TY;
+  const char *const ldsb = reinterpret_cast<const char *>(lds);
+  int tr0 = 0, tc0 = wave;
+  while (tc0 >= p.TXT) { tc0 -= p.TXT; ++tr0; }
+  for (int t = wave; t < ntiles; t += 8) {
+    int tr1 = tr0, tc1 = tc0 + 4;
+    while (tc1 >= p.TXT) { tc1 -= p.TXT; ++tr1; }
+    const bool two = t + 4 < ntiles;
+    if (!two) { tr1 = tr0; tc1 = tc0; }
+    const bool ok0 = zok && tc0 * 16 + m < p.OW && oy0 + tr0 < p.OH;
+    const bool ok1 = zok && two && tc1 * 16 + m < p.OW && oy0 + tr1 < p.OH;
+    int oo0 = ok0 ? obase + (tr0 * p.oH + tc0 * 16 * p.oW) * 2 : OOB, oo1 = ok1 ? obase + (tr1 * p.oH + tc1 * 16 * p.oW) * 2 : OOB;
+    u32x2 g0 = {0u, 0u}, g1 = g0;
+    if (EPI == 1) {
+      const int go0 = ok0 ? gbase + (tr0 * p.gH + tc0 * 16 * p.gW) * 2 : OOB, go1 = ok1 ? gbase + (tr1 * p.gH + tc1 * 16 * p.gW) * 2 : OOB;
+      g0 = __builtin_amdgcn_raw_buffer_load_b64(grs, go0, 0, 0);
+      g1 = __builtin_amdgcn_raw_buffer_load_b64(grs, go1, 0, 0);
+    }
+    const int tb0 = (tr0 * p.colsP + tc0 * 16) * 4, tb1 = (tr1 * p.colsP + tc1 * 16) * 4;
+    float a0[KS], a1[KS];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const float *s0 = reinterpret_cast<const float *>(ldsb + rowoff[j] + tb0), *s1 = reinterpret_cast<const float *>(ldsb + rowoff[j] + tb1);
+      a0[3 * j] = s0[0]; a0[3 * j + 1] = s0[1]; a0[3 * j + 2] = s0[2];
+      a1[3 * j] = s1[0]; a1[3 * j + 1] = s1[1]; a1[3 * j + 2] = s1[2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(B[s], a0[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(B[s], a1[s], acc1, 0, 0, 0);
+    }
+    float v0[4], v1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v0[c] = acc0[c]; v1[c] = acc1[c];
+      if (EPI == 1) {
+        const uint32_t h0 = (c & 1) ? (g0[c >> 1] & 0xffff0000u) : (g0[c >> 1] << 16), h1 = (c & 1) ? (g1[c >> 1] & 0xffff0000u) : (g1[c >> 1] << 16);
+        v0[c] = __uint_as_float(h0) > 0.f ? v0[c] : p.gate_slope * v0[c];
+        v1[c] = __uint_as_float(h1) > 0.f ? v1[c] : p.gate_slope * v1[c];
+      } else {
+        v0[c] = v0[c] > 0.f ? v0[c] : p.slope * v0[c];
+        v1[c] = v1[c] > 0.f ? v1[c] : p.slope * v1[c];
+      }
+    }
+    auto pk = [](float a, float b_) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{a, b_}, bf16x2_)); };
+    asm volatile("" : "+v"(oo0), "+v"(oo1));
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk(v0[0], v0[1]), pk(v0[2], v0[3])}, ors, oo0, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk(v1[0], v1[1]), pk(v1[2], v1[3])}, ors, oo1, 0, 0);
+    tc0 += 8;
+    while (tc0 >= p.TXT) { tc0 -= p.TXT; ++tr0; }
+  }
+}
+
+template <int CO, bool FLIP>
+static int run_mfma_h(const Dev &q, int N, hipStream_t st, bool dry, char *name, int name_len) {
+  constexpr int NZ = CO == 8 ? 2 : 1, NP = NZ + 2;
+  DevM p{};
+  if (q.iW != 1 || q.W % 4 || q.iH % 2 || q.iD % 2 || q.iN % 2 || ((uintptr_t)q.in & 3)) return TEM_EUNSUPPORTED;   // 8-byte loads of 4 voxels
+  p.in = q.in; p.iN = q.iN; p.iD = q.iD; p.iH = q.iH; p.D = q.D; p.H = q.H; p.W = q.W;
+  {
+    const int64_t span = ((int64_t)(N - 1) * q.iN + (int64_t)(q.D - 1) * q.iD + (int64_t)(q.H - 1) * q.iH + q.W) * 2;
+    if (span >= ((int64_t)1 << 31)) return TEM_EUNSUPPORTED;
+    p.in_bytes = (int)span;
+  }
+  p.out = q.out; p.oN = q.oN; p.oD = q.oD; p.oH = q.oH; p.oW = q.oW; p.OD = q.OD; p.OH = q.OH; p.OW = q.OW;
+  p.P = q.P; p.slope = q.slope; p.gate = q.gate; p.gN = q.gN; p.gD = q.gD; p.gH = q.gH; p.gW = q.gW;
+  p.gate_slope = q.gate_slope;
+  if (q.bias) return TEM_EUNSUPPORTED;
+  if (q.gate && q.slope != 1.f) return TEM_EUNSUPPORTED;
+  {
+    const int64_t ospan = ((int64_t)(q.OD - 1) * q.oD + (int64_t)(q.OH - 1) * q.oH + (int64_t)(q.OW - 1) * q.oW + CO) * 2;
+    const int64_t gspan = q.gate ? ((int64_t)(q.OD - 1) * q.gD + (int64_t)(q.OH - 1) * q.gH + (int64_t)(q.OW - 1) * q.gW + CO) * 2 : 0;
+    if (ospan >= ((int64_t)1 << 31) || gspan >= ((int64_t)1 << 31)) return TEM_EUNSUPPORTED;
+    p.out_bytes = (int)ospan; p.gate_bytes = (int)gspan;
+  }
+  p.TXT = (p.OW + 15) / 16;
+  p.xs = p.P <= 0 ? (-p.P / 4) * 4 : -((p.P + 3) / 4) * 4;
+  p.sh = -p.P - p.xs;
+  p.colsP = p.TXT * 16 + 16;
+  p.cpr = p.colsP / 4;
+  p.TY = (64 + p.TXT - 1) / p.TXT;
+  if (p.TY > p.OH) p.TY = p.OH;
+  while (p.TY > 1 && (p.TY + 2) * p.cpr > 2 * 256) --p.TY;
+  if ((p.TY + 2) * p.cpr > 2 * 256) return TEM_EUNSUPPORTED;
+  p.nty = (p.OH + p.TY - 1) / p.TY;
+  p.TY = (p.OH + p.nty - 1) / p.nty;
+  if (!(p.TY & 1) && (p.TY + 3) * p.cpr <= 2 * 256) ++p.TY;
+  p.nty = (p.OH + p.TY - 1) / p.TY;
+  p.nzg = (p.OD + NZ - 1) / NZ;
+  p.magicCpr = magic_for(p.cpr);
+  p.magicTXT = magic_for(p.TXT);
+  const size_t lds_bytes = (size_t)NP * (p.TY + 2) * p.colsP * 4;
+  if (lds_bytes > 64 * 1024) return TEM_EUNSUPPORTED;
+  if (name) snprintf(name, name_len, "c1_mfma_h_k<%d, %s, %d>", CO, FLIP ? "true" : "false", q.gate ? 1 : 0);
+  if (dry) return TEM_OK;
+  const int nblocks = N * p.nty * p.nzg;
+  const unsigned short *w = reinterpret_cast<const unsigned short *>(q.w);
+  if (q.gate) hipLaunchKernelGGL((c1_mfma_h_k<CO, FLIP, 1>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
+  else hipLaunchKernelGGL((c1_mfma_h_k<CO, FLIP, 0>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+// bf16 tensors behind the float* fields of tem_conv_args (strides in elements), `w` = the packed bf16 kernel [tap][co]
+int dispatch_h(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int name_len) {
+  const tem_view &i0 = a->in0, &o0 = a->out0;
+  if (a->in1.ptr || a->out1.ptr || i0.C != 1 || (o0.C != 8 && o0.C != 16)) return TEM_EUNSUPPORTED;
+  if (a->kd != 3 || a->kh != 3 || a->kw != 3 || a->sd != 1 || a->sh != 1 || a->sw != 1) return TEM_EUNSUPPORTED;
+  if (a->pd != a->ph || a->ph != a->pw) return TEM_EUNSUPPORTED;
+  if (a->ep.dropout || a->ep.add.ptr) return TEM_EUNSUPPORTED;
+  if (o0.N != i0.N) return TEM_ESHAPE;
+  if (!fits32(i0) || !fits32(o0)) return TEM_EUNSUPPORTED;
+  auto al8 = [](const tem_view &v) {      // 8-byte accesses of 4 bf16 channels
+    return ((uintptr_t)v.ptr & 7) == 0 && v.sW % 4 == 0 && v.sH % 4 == 0 && v.sD % 4 == 0 && v.sN % 4 == 0;
+  };
+  if (!al8(o0)) return TEM_EUNSUPPORTED;
+  Dev p{};
+  p.in = i0.ptr; p.iN = (int)i0.sN; p.iD = (int)i0.sD; p.iH = (int)i0.sH; p.iW = (int)i0.sW;
+  p.D = i0.D; p.H = i0.H; p.W = i0.W;
+  p.w = a->w;
+  p.out = o0.ptr; p.oN = (int)o0.sN; p.oD = (int)o0.sD; p.oH = (int)o0.sH; p.oW = (int)o0.sW;
+  p.OD = o0.D; p.OH = o0.H; p.OW = o0.W;
+  p.P = a->pd;
+  p.slope = a->ep.slope; p.gate_slope = a->ep.gate_slope; p.bias = a->ep.bias;
+  if (a->ep.gate.ptr) {
+    const tem_view &g = a->ep.gate;
+    if (g.N != o0.N || g.D != o0.D || g.H != o0.H || g.W != o0.W || g.C < o0.C) return TEM_ESHAPE;
+    if (!fits32(g) || !al8(g)) return TEM_EUNSUPPORTED;
+    p.gate = g.ptr; p.gN = (int)g.sN; p.gD = (int)g.sD; p.gH = (int)g.sH; p.gW = (int)g.sW;
+  }
+  const bool flip = a->w_layout == TEM_W_FLIP_CO_CI;
+  const int N = i0.N;
+  if (o0.C == 8) return flip ? run_mfma_h<8, true>(p, N, st, dry, name, name_len) : run_mfma_h<8, false>(p, N, st, dry, name, name_len);
+  return flip ? run_mfma_h<16, true>(p, N, st, dry, name, name_len) : run_mfma_h<16, false>(p, N, st, dry, name, name_len);
+}
+
 }  // namespace stencil_c1
 
 // Called by tem_conv (dispatch.hip) after the LDS/MFMA-tiled kernel declined.
@@ -560,4 +788,9 @@ int tem_conv_c1_describe(const tem_conv_args *a, char *buf, int len) {
   int rc = stencil_c1::dispatch(a, nullptr, true);
   stencil_c1::g_name = nullptr;
   return rc;
+}
+
+// bf16 mode (conv_bf16.hip tries this first for the one-input-channel layers)
+int tem_conv_c1_bf16_try(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int name_len) {
+  return stencil_c1::dispatch_h(a, st, dry, name, name_len);
 }
