@@ -60,7 +60,7 @@ def test_conv_bf16_forward(H, oracle_lib, CI, CO, k, s, pad, n):
     launch = H.conv_launch("t", devb(x), pack(w), out, k, s, pad, slope=0.3,
                            bias=torch.from_numpy(bias).cuda() if bias is not None else None)
     H.run([launch])
-    marching = k == 3 and s == 1 and CI >= 8 and CO >= 8
+    marching = CI >= 8 and CO >= 8 and ((k == 3 and s == 1) or (k == 4 and s == 2 and CI <= 16))
     assert launch.meta["kernel"].startswith("conv3_bf16_k" if marching else "conv_bf16_k")
     assert rel_err(out.float().cpu().numpy(), ref) < TOL
 
@@ -119,6 +119,33 @@ def test_conv3_bf16_marching_kernel(H, oracle_lib, CI, CO):
                            add=devb(addw), add_off=1)
     H.run([launch])
     assert launch.meta["kernel"].startswith("conv3_bf16_k")
+    assert rel_err(out.float().cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("CI,CO", [(8, 8), (8, 16), (16, 16), (16, 32)])
+def test_conv3_bf16_marching_kernel_k4s2(H, oracle_lib, CI, CO):
+    """conv3_bf16_k<.., 4, 2, ..>: the 4x4x4 stride-2 form (6-slot ring, two new planes per step, tile pairs inside an output
+    row): padded forward on a ragged batch-2 volume, and an un-padded launch with gate + skip-gradient window."""
+    rng = np.random.default_rng(CI * 10 + CO)
+    x = rb(rnd(rng, 2, 12, 22, 70, CI))
+    w = rb(rnd(rng, 4, 4, 4, CI, CO) * 0.1)
+    ref = oracle_lib.leaky_relu(oracle_lib.conv_fwd(x, w, 2, 1, None))
+    out = torch.empty(ref.shape, dtype=torch.bfloat16, device="cuda")
+    launch = H.conv_launch("t", devb(x), pack(w), out, 4, 2, 1, slope=0.3)
+    H.run([launch])
+    assert launch.meta["kernel"].startswith("conv3_bf16_k"), launch.meta["kernel"]
+    assert rel_err(out.float().cpu().numpy(), ref) < TOL
+    x = rb(rnd(rng, 1, 10, 16, 36, CI))
+    full = oracle_lib.conv_fwd(x, w, 2, 0, None)
+    saved = rb(rnd(rng, *full.shape))
+    addw = rb(rnd(rng, 1, full.shape[1] - 2, full.shape[2] - 2, full.shape[3] - 2, CO))
+    ref = full.copy()
+    ref[:, 1:-1, 1:-1, 1:-1, :] += addw
+    ref = oracle_lib.leaky_relu_grad_from_out(ref, saved)
+    out = torch.empty(ref.shape, dtype=torch.bfloat16, device="cuda")
+    launch = H.conv_launch("t", devb(x), pack(w), out, 4, 2, 0, gate=devb(saved), add=devb(addw), add_off=1)
+    H.run([launch])
+    assert launch.meta["kernel"].startswith("conv3_bf16_k"), launch.meta["kernel"]
     assert rel_err(out.float().cpu().numpy(), ref) < TOL
 
 

@@ -1,4 +1,5 @@
-// conv3_bf16.hip -- 3x3x3 stride-1 convolution forward / input-gradient of the bf16 mode (BASELINE config 5), z-marching.
+// conv3_bf16.hip -- 3x3x3 stride-1 and 4x4x4 stride-2 convolution forward / input-gradient of the bf16 mode (BASELINE
+// config 5), z-marching.
 //
 // The shape-generic conv_bf16_k spends ~500 vector instructions per 16-voxel tile (index arithmetic, the LDS transpose
 // of its epilogue, a kernel copy staged per output plane) around 14..54 matrix instructions -- vector and matrix
@@ -71,11 +72,12 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));     // round to nearest even
 }
 
-template <int CI, int CO, int NW, bool SPLIT, int EPI>
+template <int CI, int CO, int K, int S, int NW, bool SPLIT, int EPI>
 __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
   // SPLIT: the n-tiles of a 32-channel output go to different waves (kernel fragments of both would not fit the registers)
-  constexpr int NSTEP = (27 * CI + 31) / 32, NTA = (CO + 15) / 16, NT = SPLIT ? 1 : NTA, NPG = SPLIT ? NW / NTA : NW;
-  constexpr int CPV = CI / 8, TILEB = 32 * CI;
+  constexpr int NTAP = K * K * K, NSTEP = (NTAP * CI + 31) / 32, NTA = (CO + 15) / 16, NT = SPLIT ? 1 : NTA, NPG = SPLIT ? NW / NTA : NW;
+  constexpr int CPV = CI / 8, TILEB = S * 32 * CI;           // bytes between the B fragments of x-adjacent tiles
+  static_assert((K == 3 && S == 1) || (K == 4 && S == 2), "3x3x3 stride 1 or 4x4x4 stride 2");
   constexpr int MAXJ = 40;                                  // LDS-DMA instructions per plane (slot <= 40 KB)
   static_assert(CI == 8 || CI == 16 || CI == 32, "8 / 16 / 32 input channels");
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
@@ -110,14 +112,14 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
       asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(off), "s"(rs) : "memory");
     };
     int voff[MAXJ], vzs[MAXJ];
-    const int iz_first = oz0 - p.P;
+    const int iz_first = S * oz0 - p.P;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       if (j < p.ndma) {                                         // (wave-uniform)
         const int g = 64 * j + lane;
         const int v = g / CPV, h = g & (CPV - 1);
         const int r = (int)(((uint32_t)v * p.magicRW) >> 22), cx = v - r * RW;
-        const int iy = oy0 - p.P + r, ix = ox0 - p.P + cx;
+        const int iy = S * oy0 - p.P + r, ix = S * ox0 - p.P + cx;
         const bool ok = v < p.PV && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const int c = 8 * h;
         const bool s0 = c < p.C0;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
     }
     int slot = 1;
     auto dma = [&](int k) {                                    // input plane oz0 - P + k -> the next slot of the ring
-      const int iz = oz0 - p.P + k;
+      const int iz = S * oz0 - p.P + k;
       const bool zok = (unsigned)iz < (unsigned)p.D;
       const uint32_t dst = ring0 + slot * SB;
       slot = slot + 1 == p.RD ? 0 : slot + 1;
@@ -137,14 +139,14 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
       for (int j = 0; j < MAXJ; ++j)
         if (j < p.ndma && !(p.dbg & 4)) issue(dst + j * 1024, voff[j] + iz * vzs[j], zok);
     };
-    // RD - 3 planes stay in flight: the bytes a CU must keep outstanding to draw its share of the HBM rate (~48 KB at
-    // ~2.5 us) are several planes of a column.  vmcnt returns in order, so "planes <= j + 2 have landed" is
-    // vmcnt <= (planes issued after j + 2) x ndma -- an immediate, hence the switch (the host keeps it below 64).
-    const int PF = p.RD - 3, last = nz + 1;
+    // Step j (output plane oz0 + j) reads the planes S j .. S j + K - 1; the ring has RD >= K + S slots, so the planes up to
+    // S j + RD - 1 may be in it or in flight.  vmcnt returns in order, so "planes <= S j + K - 1 have landed" is
+    // vmcnt <= (planes issued after them) x ndma -- an immediate, hence the switch (the host keeps it below 64).
+    const int last = S * (nz - 1) + K - 1;
     int issued = 0;                                            // last plane issued
-    while (issued < last && issued < PF + 1) dma(++issued);
+    while (issued < last && issued < p.RD - 1) dma(++issued);
     for (int j = 0; j < nz; ++j) {
-      const int fly = (issued - (j + 2)) * p.ndma;
+      const int fly = (issued - (S * j + K - 1)) * p.ndma;
       switch (fly > 0 ? fly : 0) {
 #define TEM_W1(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 #define TEM_W8(a) TEM_W1(a##0) TEM_W1(a##1) TEM_W1(a##2) TEM_W1(a##3) TEM_W1(a##4) TEM_W1(a##5) TEM_W1(a##6) TEM_W1(a##7)
@@ -159,9 +161,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
 #undef TEM_W8
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
       }
-      // planes j .. j+2 have landed; past the barrier nobody reads the slot of plane j-1 any more
+      // the step's planes have landed; past the barrier nobody reads the planes below S j any more
       asm volatile("s_barrier" ::: "memory");
-      if (issued < last) dma(++issued);
+      while (issued < last && issued < S * j + p.RD - 1) dma(++issued);
     }
     return;
   }
@@ -175,7 +177,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
     for (int nt = 0; nt < NT; ++nt) {
       const int co = (ntb + nt) * 16 + m;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (tap < 27 && co < CO) v = *reinterpret_cast<const u32x4 *>(p.w + ((p.flip ? 26 - tap : tap) * CO + co) * CI + c0);
+      if (tap < NTAP && co < CO) v = *reinterpret_cast<const u32x4 *>(p.w + ((p.flip ? NTAP - 1 - tap : tap) * CO + co) * CI + c0);
       wf[s][nt] = __builtin_bit_cast(bf16x8, v);
     }
   }
@@ -185,9 +187,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
     const int e0 = 32 * s + 8 * kq;
-    const int tap = min(e0 / CI, 26), h = (e0 % CI) >> 3;   // (a padded k-range multiplies zero kernel rows: any address)
-    const int dz = tap / 9, dy = (tap - 9 * dz) / 3, dx = tap - 9 * dz - 3 * dy;
-    const int vrel = m + dy * RW + dx;
+    const int tap = min(e0 / CI, NTAP - 1), h = (e0 % CI) >> 3;   // (a padded k-range multiplies zero kernel rows: any address)
+    const int dz = tap / (K * K), dy = (tap - K * K * dz) / K, dx = tap - K * K * dz - K * dy;
+    const int vrel = S * m + dy * RW + dx;
     cur[s] = ring0 + dz * SB + (vrel * CPV + h) * 16;
   }
 
@@ -217,8 +219,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
   const int axl = ox0 - p.aox + m;                             // this lane's column of the skip-gradient window, tile at x0 = 0
   const float gs = p.gate_slope;
   const f32x2 slope2 = f32x2{p.slope, p.slope};
-  const int TPR = RW >> 4;                                     // tiles per ring row
-  const int ntile = TYo * TPR, npair = (ntile + 1) >> 1;
+  // stride 1: the ring row is a multiple of 16 voxels and the tiles run flat over the rows (a pair may span two rows);
+  // stride 2: tiles are 16 output voxels = 32 input voxels of a ring row, pairs stay inside an output row
+  const int TPR = S == 1 ? RW >> 4 : (p.TX + 31) >> 5;        // tiles (stride 2: tile pairs; an edge column masks the surplus) per row
+  const int npair = S == 1 ? (TYo * TPR + 1) >> 1 : TYo * TPR;
 
   // (the kernel / bias loads are consumed here, in front of the loops: left pending into the loop, their first use
   // inside it gets s_waitcnt vmcnt(0) in every iteration -- the waitcnt pass cannot tell that they landed long ago)
@@ -230,7 +234,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
   for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bias4[nt]));
   const uint32_t ring_len = (uint32_t)p.RD * (uint32_t)SB, ring_end = ring0 + ring_len;
   for (int j = 0; j < nz; ++j) {
-    asm volatile("s_barrier" ::: "memory");                // the producer's: planes j .. j+2 are in the ring
+    asm volatile("s_barrier" ::: "memory");                // the producer's: the step's K input planes are in the ring
     const int oz = oz0 + j;
     const int az = oz - p.aoz;
     const __amdgpu_buffer_rsrc_t ars =
@@ -241,12 +245,22 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
     const int sk_z = ((n * p.dD + oz + p.doz) * p.dH + p.doy + oy0) * p.dW + ox0 + p.dox;       // voxel index of the dropout tensor
     for (int pi = pg; pi < npair; pi += NPG) {                  // wave-uniform
       int rr[2], x0[2], rem[2];
+      uint32_t toff;                                            // byte offset of the pair's first B fragment in a ring plane
+      if constexpr (S == 1) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int t = 2 * pi + i;
-        rr[i] = TPR == 1 ? t : (int)__umulhi((uint32_t)t, p.magicT);    // (the magic of 1 does not fit 32 bits)
-        x0[i] = (t - rr[i] * TPR) << 4;
-        rem[i] = rr[i] < TYo ? TXo - x0[i] : 0;                 // columns of the tile that are output voxels
+        for (int i = 0; i < 2; ++i) {
+          const int t = 2 * pi + i;
+          rr[i] = TPR == 1 ? t : (int)__umulhi((uint32_t)t, p.magicT);    // (the magic of 1 does not fit 32 bits)
+          x0[i] = (t - rr[i] * TPR) << 4;
+          rem[i] = rr[i] < TYo ? TXo - x0[i] : 0;               // columns of the tile that are output voxels
+        }
+        toff = (uint32_t)pi * (2 * TILEB);
+      } else {
+        rr[0] = TPR == 1 ? pi : (int)__umulhi((uint32_t)pi, p.magicT);
+        rr[1] = rr[0];
+        x0[0] = (pi - rr[0] * TPR) << 5; x0[1] = x0[0] + 16;
+        rem[0] = TXo - x0[0]; rem[1] = TXo - x0[1];
+        toff = (uint32_t)((S * rr[0] * RW + S * x0[0]) * (CI * 2));
       }
       if (rem[0] > 0 || rem[1] > 0) {
         u32x2 gv[2][NT], av[2][NT];
@@ -275,7 +289,6 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
         // B fragments PD k-steps ahead of their matrix instructions (sched_barrier: hipcc otherwise sinks each read to
         // its use and waits lgkmcnt(0) in front of every instruction of the chain)
         constexpr int PD = NSTEP < 4 ? NSTEP : 4;
-        const uint32_t toff = (uint32_t)pi * (2 * TILEB);
         if (!(p.dbg & 2)) {
           typedef const __attribute__((address_space(3))) u32x4 *lptr;
           u32x4 bq[NSTEP][2];
@@ -338,7 +351,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
     // next step: the planes move one slot on
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-      cur[s] += (uint32_t)SB;
+      cur[s] += (uint32_t)(S * SB);
       if (cur[s] >= ring_end) cur[s] -= ring_len;
     }
   }
@@ -350,9 +363,9 @@ static int64_t span(const tem_view &v) {
   return (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH + (int64_t)(v.W - 1) * v.sW + v.C;
 }
 
-template <int CI, int CO, int NW, bool SPLIT, int EPI>
+template <int CI, int CO, int K, int S, int NW, bool SPLIT, int EPI>
 static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len) {
-  constexpr int NSTEP = (27 * CI + 31) / 32, CPV = CI / 8, MAXJ = 40, NPG = SPLIT ? NW / ((CO + 15) / 16) : NW;
+  constexpr int NSTEP = (K * K * K * CI + 31) / 32, CPV = CI / 8, MAXJ = 40, NPG = SPLIT ? NW / ((CO + 15) / 16) : NW;
   // output column (TX x TY) and z segments: fewest rounds of (march length + ring prologue) x tile pairs per wave
   double best = 1e30;
   const int knob_ty = tem_env_int("TEM_C3B_TY", 0), knob_nbx = tem_env_int("TEM_C3B_NBX", 0), knob_zs = tem_env_int("TEM_C3B_ZSEGS", 0);
@@ -361,29 +374,30 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
     if (knob_nbx && nbx != knob_nbx) continue;
     const int TX = (p.OW + nbx - 1) / nbx;
     if (nbx > 1 && TX < 16) break;
-    const int RW = (TX + 2 + 15) & ~15;                        // a tile (16 voxels) never straddles ring rows
+    // stride 1: a tile (16 voxels) never straddles ring rows; stride 2: the row holds the 2 TX + 2 input columns
+    const int RW = S == 1 ? (TX + 2 + 15) & ~15 : (S * (TX - 1) + K + 1) & ~1;
     for (int TY = 2; TY <= 24 && TY <= p.OH + 1; ++TY) {
       if (knob_ty && TY != knob_ty) continue;
-      const int PV = (TY + 2) * RW;
-      const int slot = (int)((((int64_t)(PV + 33) * CI * 2) + 1023) & ~(int64_t)1023);
+      const int PV = (S * (TY - 1) + K) * RW;
+      const int slot = (int)((((int64_t)(PV + S * 32 + K + 1) * CI * 2) + 1023) & ~(int64_t)1023);     // + the last pair's over-read
       const int ndma = (PV * CPV + 63) / 64;
       if (ndma > MAXJ) continue;
       const int nby = (p.OH + TY - 1) / TY;
       const int cols = N * nbx * nby;
-      const int pairs = ((TY * (RW / 16) + 1) / 2 + NPG - 1) / NPG;
+      const int pairs = ((S == 1 ? (TY * (RW / 16) + 1) / 2 : TY * ((TX + 31) / 32)) + NPG - 1) / NPG;
       // measured (tests/tools/c3b_sweep.py): ~3 us of launch + column start-up, a step costs its barrier plus, per tile pair,
       // the matrix chain and ~500 cycles of scalar / epilogue work; deeper rings (more planes in flight) bought nothing
       const double step = 1000.0 + pairs * (2.0 * NSTEP * 16.0 * ((CO + 15) / 16) + 500.0);
-      for (int RD = 4; RD <= 8; ++RD) {
-        if (knob_rd ? RD != knob_rd : RD != 4) continue;
-        if (RD * slot > LDS_MAX || (RD - 4) * ndma > 62) continue;
+      for (int RD = K + S; RD <= 8; ++RD) {
+        if (knob_rd ? RD != knob_rd : RD != K + S) continue;
+        if (RD < K + S || RD * slot > LDS_MAX || (RD - K) * ndma > 62) continue;
         for (int zsegs = 1; zsegs <= p.OD; ++zsegs) {
           if (knob_zs && zsegs != knob_zs) continue;
           const int zper = (p.OD + zsegs - 1) / zsegs, zs = (p.OD + zper - 1) / zper;
           if (zs != zsegs) continue;
           const int64_t wgs = (int64_t)cols * zs;
           const double rounds = (double)((wgs + 255) / 256);
-          const double cost = rounds * ((zper + 2) * step + 7000.0);
+          const double cost = rounds * ((zper + (K - S) / (double)S) * step + 7000.0);
           if (cost < best) {
             best = cost;
             p.TX = TX; p.TY = TY; p.nbx = nbx; p.nby = nby; p.zsegs = zs; p.zper = zper;
@@ -396,13 +410,16 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
   if (best >= 1e30) return TEM_EUNSUPPORTED;
   p.dbg = tem_env_int("TEM_C3B_DBG", 0);
   p.magicRW = (uint32_t)(((1u << 22) + p.RW - 1) / p.RW);
-  p.magicT = (uint32_t)((((uint64_t)1 << 32) + (p.RW / 16) - 1) / (p.RW / 16));
+  {
+    const uint32_t tpr = S == 1 ? p.RW / 16 : (p.TX + 31) / 32;      // (the kernel's TPR for a full column; edge columns have fewer pairs)
+    p.magicT = (uint32_t)((((uint64_t)1 << 32) + tpr - 1) / tpr);
+  }
   {                                                                                     // (v * magic) >> 22 exact, in 32 bits
-    const int64_t vmax = (int64_t)(p.TY + 2) * p.RW + 64;
+    const int64_t vmax = (int64_t)(S * (p.TY - 1) + K) * p.RW + 64;
     if (vmax >= (1 << 22) / p.RW || vmax * p.magicRW >= ((int64_t)1 << 32) || p.magicRW >= (1u << 24)) return TEM_EUNSUPPORTED;
   }
   if (dry) {
-    if (name) snprintf(name, name_len, "conv3_bf16_k<%d, %d, %d, %s, %d>", CI, CO, NW, SPLIT ? "true" : "false", EPI);
+    if (name) snprintf(name, name_len, "conv3_bf16_k<%d, %d, %d, %d, %d, %s, %d>", CI, CO, K, S, NW, SPLIT ? "true" : "false", EPI);
     return TEM_OK;
   }
   static int dbg = -1;
@@ -412,7 +429,7 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
   if (dbg & 8)
     fprintf(stderr, "conv3_bf16<%d,%d> O=%dx%dx%d P=%d: TX=%d TY=%d RW=%d zsegs=%d zper=%d blocks=%d lds=%zu ndma=%d RD=%d\n", CI, CO, p.OD,
             p.OH, p.OW, p.P, p.TX, p.TY, p.RW, p.zsegs, p.zper, nblocks, lds, p.ndma, p.RD);
-  auto kern = conv3_bf16_k<CI, CO, NW, SPLIT, EPI>;
+  auto kern = conv3_bf16_k<CI, CO, K, S, NW, SPLIT, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
@@ -427,8 +444,9 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
 // TEM_EUNSUPPORTED: the caller falls back to conv_bf16_k
 int dispatch(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int name_len) {
   const tem_view &i0 = a->in0, &o0 = a->out0;
-  if (!(a->kd == 3 && a->kh == 3 && a->kw == 3 && a->sd == 1 && a->sh == 1 && a->sw == 1 && a->pd == a->ph && a->ph == a->pw))
-    return TEM_EUNSUPPORTED;
+  const bool k3s1 = a->kd == 3 && a->kh == 3 && a->kw == 3 && a->sd == 1 && a->sh == 1 && a->sw == 1;
+  const bool k4s2 = a->kd == 4 && a->kh == 4 && a->kw == 4 && a->sd == 2 && a->sh == 2 && a->sw == 2;
+  if (!((k3s1 || k4s2) && a->pd == a->ph && a->ph == a->pw)) return TEM_EUNSUPPORTED;
   if (a->ep.dropout && !(a->ep.keep_mask && a->ep.keep_mode == 2)) return TEM_EUNSUPPORTED;     // reads a keep mask, draws none
   if (o0.N != i0.N) return TEM_ESHAPE;
   auto U = [](const float *q) { return reinterpret_cast<const u16 *>(q); };
@@ -484,7 +502,10 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int n
     p.outb = (u16 *)lo; p.oo0 = (int)(q0 - lo); p.oo1 = (int)(q1 - lo); p.out_bytes = (uint32_t)end;
   }
   p.OD = o0.D; p.OH = o0.H; p.OW = o0.W;
-  if (p.OD != p.D + 2 * p.P - 2 || p.OH != p.H + 2 * p.P - 2 || p.OW != p.W + 2 * p.P - 2) return TEM_ESHAPE;
+  {
+    const int K = k3s1 ? 3 : 4, S = k3s1 ? 1 : 2;
+    if (p.OD != (p.D + 2 * p.P - K) / S + 1 || p.OH != (p.H + 2 * p.P - K) / S + 1 || p.OW != (p.W + 2 * p.P - K) / S + 1) return TEM_ESHAPE;
+  }
   const tem_epilogue &e = a->ep;
   p.bias = e.bias; p.slope = e.slope; p.gate_slope = e.gate_slope;
   if (e.bias && o0.C % 4) return TEM_EUNSUPPORTED;
@@ -516,12 +537,15 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int n
   const bool lmax = p.slope > 0.f && p.slope < 1.f;
   if (p.slope != 1.f && !(lmax && !p.gate && !p.add && !p.keep)) return TEM_EUNSUPPORTED;    // LeakyReLU only without gate / add / mask
   const int epi = (p.gate ? 1 : 0) | (p.add ? 2 : 0) | (p.keep ? 4 : 0) | (lmax ? 8 : 0);
-#define C3E(ci, co, nw, sp, ep) if (CI == ci && CO == co && epi == ep) return run<ci, co, nw, sp, ep>(p, N, st, dry, name, name_len);
-#define C3(ci, co, nw, sp) C3E(ci, co, nw, sp, 8) C3E(ci, co, nw, sp, 0) C3E(ci, co, nw, sp, 1) C3E(ci, co, nw, sp, 3) C3E(ci, co, nw, sp, 5) \
-                           C3E(ci, co, nw, sp, 7)
-  if (tem_env_int("TEM_C3B_NW", 8) == 4) { C3(8, 8, 4, false) C3(16, 16, 4, false) }
-  C3(8, 8, 8, false) C3(8, 16, 8, false) C3(16, 8, 8, false) C3(16, 16, 8, false) C3(16, 32, 4, false) C3(32, 16, 4, false)
-  C3(32, 32, 4, true)
+#define C3E(ci, co, k, s, nw, sp, ep) \
+  if (CI == ci && CO == co && (k == 3) == k3s1 && epi == ep) return run<ci, co, k, s, nw, sp, ep>(p, N, st, dry, name, name_len);
+#define C3(ci, co, k, s, nw, sp) C3E(ci, co, k, s, nw, sp, 8) C3E(ci, co, k, s, nw, sp, 0) C3E(ci, co, k, s, nw, sp, 1) \
+                                 C3E(ci, co, k, s, nw, sp, 3) C3E(ci, co, k, s, nw, sp, 5) C3E(ci, co, k, s, nw, sp, 7)
+  C3(8, 8, 3, 1, 8, false) C3(8, 16, 3, 1, 8, false) C3(16, 8, 3, 1, 8, false) C3(16, 16, 3, 1, 8, false) C3(16, 32, 3, 1, 4, false)
+  C3(32, 16, 3, 1, 4, false) C3(32, 32, 3, 1, 4, true)
+  // 4x4x4 stride 2 (Downsample blocks; input-gradients of the transposed convolutions): 16 / 32 k-steps of kernel fragments in
+  // registers; 32 input channels (64 k-steps) stay on conv_bf16_k
+  C3(8, 8, 4, 2, 8, false) C3(8, 16, 4, 2, 8, false) C3(16, 16, 4, 2, 4, false) C3(16, 32, 4, 2, 4, true)
 #undef C3E
 #undef C3
   return TEM_EUNSUPPORTED;
