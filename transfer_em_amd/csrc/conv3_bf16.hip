@@ -40,16 +40,15 @@ constexpr int OOB = (int)0x80000000;
 constexpr int LDS_MAX = 160 * 1024;
 
 struct Dev {
-  const u16 *inb;                  // buffer base of the input tensor(s): the lower of in0 / in1
-  uint32_t in_bytes;
-  int32_t off0, off1;              // byte offsets of in0 / in1 from inb
+  const u16 *in0, *in1;            // (a descriptor each: which kernel runs must not depend on where the allocator put the two
+  uint32_t in0_bytes, in1_bytes;   //  inputs of a concat -- a single descriptor over both needs them within 2 GB)
+  int32_t ndma_cnt;                // vmcnt events per plane: ndma, twice that for a concat (a wave issues for in0 and for in1)
   int32_t i0N, i0D, i0H, i0W, i1N, i1D, i1H, i1W, C0;
   int32_t D, H, W, P;
   const u16 *w;                    // packed bf16 kernel [tap][co][ci]
   int32_t flip;
-  u16 *outb;                       // buffer base of the output tensor(s): the lower of out0 / out1 (equal strides)
-  uint32_t out_bytes;
-  int32_t oo0, oo1;                // byte offsets of out0 / out1 from outb
+  u16 *out0, *out1;                // split outputs: equal strides (one scalar offset per tile), a descriptor each
+  uint32_t out0_bytes, out1_bytes;
   int32_t oN, oD, oH, oW, CO0;
   int32_t OD, OH, OW;
   int32_t TX, TY, nbx, nby, zsegs, zper;
@@ -105,16 +104,21 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
   // [64 j, 64 j + 64) of the slot.  (Inline assembly: for the builtin, hipcc cannot tell the ring slots apart and puts
   // s_waitcnt vmcnt(0) in front of the first LDS read after it.)
   if (wave == NW) {
-    const uint32_t rs_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p.inb);
-    const uint32_t rs_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p.inb >> 32) & 0xffffu);
-    auto issue = [&](uint32_t dst, int off, bool zok) {
-      const u32x4 rs = u32x4{rs_lo, rs_hi, zok ? p.in_bytes : 0u, 0x00020000u};
-      asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(off), "s"(rs) : "memory");
-    };
-    int voff[MAXJ], vzs[MAXJ];
-    const int iz_first = S * oz0 - p.P;
+    const uint32_t r0_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p.in0), r0_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p.in0 >> 32) & 0xffffu);
+    const uint32_t r1_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p.in1), r1_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p.in1 >> 32) & 0xffffu);
+    // (a lane's chunk index inside a voxel is the same for every instruction -- 64 j is a multiple of the chunks per voxel -- so
+    // which input of a concat it reads and that input's plane stride are lane constants)
+    const bool s0 = (lane & (CPV - 1)) * 8 < p.C0;
+    const int zsl = (s0 ? p.i0D : p.i1D) * 2;
+    const bool concat = p.in1 != p.in0;                        // kernel-uniform
+    // one instruction per chunk row, two for a concat (the lanes of in0, then the lanes of in1: the descriptor is scalar).  The
+    // in1 lanes are switched on by their EXEC mask inside the assembly -- as a divergent branch per instruction the unrolled
+    // producer grew to 15,000 lines and its instruction fetch, not the DMA, paced the ring (g.d1b 17 -> 29 us)
+    const uint64_t m1 = __builtin_amdgcn_ballot_w64(!s0), m0 = ~m1;
+    int voff[MAXJ];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
+      voff[j] = OOB;
       if (j < p.ndma) {                                         // (wave-uniform)
         const int g = 64 * j + lane;
         const int v = g / CPV, h = g & (CPV - 1);
@@ -122,31 +126,45 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
         const int iy = S * oy0 - p.P + r, ix = S * ox0 - p.P + cx;
         const bool ok = v < p.PV && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const int c = 8 * h;
-        const bool s0 = c < p.C0;
-        voff[j] = !ok ? OOB : s0 ? p.off0 + (n * p.i0N + iy * p.i0H + ix * p.i0W + c) * 2
-                                 : p.off1 + (n * p.i1N + iy * p.i1H + ix * p.i1W + (c - p.C0)) * 2;
-        vzs[j] = !ok ? 0 : (s0 ? p.i0D : p.i1D) * 2;
-        if (!(p.dbg & 4)) issue(ring0 + j * 1024, voff[j] + iz_first * vzs[j], (unsigned)iz_first < (unsigned)p.D);    // plane 0 -> slot 0, at once
+        if (ok) voff[j] = s0 ? (n * p.i0N + iy * p.i0H + ix * p.i0W + c) * 2 : (n * p.i1N + iy * p.i1H + ix * p.i1W + (c - p.C0)) * 2;
       }
     }
-    int slot = 1;
-    auto dma = [&](int k) {                                    // input plane oz0 - P + k -> the next slot of the ring
+    int slot = 0;
+    auto dma = [&](int k) {                                    // input plane S oz0 - P + k -> the next slot of the ring
       const int iz = S * oz0 - p.P + k;
       const bool zok = (unsigned)iz < (unsigned)p.D;
       const uint32_t dst = ring0 + slot * SB;
       slot = slot + 1 == p.RD ? 0 : slot + 1;
+      const int zo = iz * zsl;
+      // (a chunk outside the input keeps its out-of-range offset: 0x80000000 + zo, zo >= 0 for a plane inside the input -- planes
+      // outside it get a zero-length descriptor -- is still beyond every range; a compare per chunk would live in 40 scalar
+      // register pairs and spill.  Descriptors and the concat decision once per plane: the producer's ~6 instructions per DMA
+      // are what keeps it ahead of the compute waves -- at ~25 it paced the ring: g.f1 31 -> 42 us)
+      const u32x4 ra = u32x4{r0_lo, r0_hi, zok ? p.in0_bytes : 0u, 0x00020000u};
+      if (p.dbg & 4) return;
+      if (!concat) {
 #pragma unroll
-      for (int j = 0; j < MAXJ; ++j)
-        if (j < p.ndma && !(p.dbg & 4)) issue(dst + j * 1024, voff[j] + iz * vzs[j], zok);
+        for (int j = 0; j < MAXJ; ++j)
+          if (j < p.ndma)
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst + j * 1024), "v"(voff[j] + zo), "s"(ra) : "memory");
+      } else {
+        const u32x4 rb = u32x4{r1_lo, r1_hi, zok ? p.in1_bytes : 0u, 0x00020000u};
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)
+          if (j < p.ndma)
+            asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, %4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                         "s_mov_b64 exec, %5\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b64 exec, -1"
+                         ::"s"(dst + j * 1024), "v"(voff[j] + zo), "s"(ra), "s"(rb), "s"(m0), "s"(m1) : "memory");
+      }
     };
     // Step j (output plane oz0 + j) reads the planes S j .. S j + K - 1; the ring has RD >= K + S slots, so the planes up to
     // S j + RD - 1 may be in it or in flight.  vmcnt returns in order, so "planes <= S j + K - 1 have landed" is
     // vmcnt <= (planes issued after them) x ndma -- an immediate, hence the switch (the host keeps it below 64).
     const int last = S * (nz - 1) + K - 1;
-    int issued = 0;                                            // last plane issued
-    while (issued < last && issued < p.RD - 1) dma(++issued);
-    for (int j = 0; j < nz; ++j) {
-      const int fly = (issued - (S * j + K - 1)) * p.ndma;
+    int issued = -1;                                           // last plane issued
+    for (int j = -1; j < nz; ++j) {                            // (j = -1: the prologue -- ONE inlined copy of the unrolled dma())
+      const int fly = j < 0 ? -1 : (issued - (S * j + K - 1)) * p.ndma_cnt;
+      if (j >= 0)
       switch (fly > 0 ? fly : 0) {
 #define TEM_W1(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 #define TEM_W8(a) TEM_W1(a##0) TEM_W1(a##1) TEM_W1(a##2) TEM_W1(a##3) TEM_W1(a##4) TEM_W1(a##5) TEM_W1(a##6) TEM_W1(a##7)
@@ -162,8 +180,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
       }
       // the step's planes have landed; past the barrier nobody reads the planes below S j any more
-      asm volatile("s_barrier" ::: "memory");
-      while (issued < last && issued < S * j + p.RD - 1) dma(++issued);
+      if (j >= 0) asm volatile("s_barrier" ::: "memory");
+      const int upto = (j < 0 ? 0 : S * j) + p.RD - 1;
+#pragma unroll 1
+      while (issued < last && issued < upto) dma(++issued);
     }
     return;
   }
@@ -198,7 +218,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
   // splits into a per-lane constant (m, channel; out of range for a lane without a role) and a SCALAR part that rides in
   // the buffer instructions' soffset -- no vector instruction per tile for addresses.
   constexpr bool GATE = EPI & 1, ADD = EPI & 2, KEEP = EPI & 4, LEAKY = EPI & 8;      // LEAKY: 0 < slope < 1, max(v, slope v)
-  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)p.outb, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ors0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.out0, 0, p.out0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ors1 = __builtin_amdgcn_make_buffer_rsrc((void *)p.out1, 0, p.out1_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)p.gate, 0, GATE ? p.gbytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.keep, 0, KEEP ? p.mbytes : 0, 0x00020000);
   int vo[NT], vg[NT], va[NT], vk[NT];
@@ -209,13 +230,14 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
     const int eco = (ntb + nt) * 16 + 4 * kq;
     const bool live = eco < CO;
     first[nt] = eco < p.CO0;
-    vo[nt] = !live ? OOB : (first[nt] ? p.oo0 + eco * 2 : p.oo1 + (eco - p.CO0) * 2) + m * p.oW * 2;
+    vo[nt] = !live ? OOB : (first[nt] ? eco * 2 : (eco - p.CO0) * 2) + m * p.oW * 2;
     vg[nt] = (live && first[nt]) ? (eco + m * p.gW) * 2 : OOB;
     va[nt] = (eco + m * p.aW) * 2;
     vk[nt] = (live && first[nt]) ? (m * p.CO0 + eco) >> 3 : OOB;
     bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias && first[nt] && live) bias4[nt] = f32x4{p.bias[eco], p.bias[eco + 1], p.bias[eco + 2], p.bias[eco + 3]};
   }
+  const bool split = p.out1 != p.out0;
   const int axl = ox0 - p.aox + m;                             // this lane's column of the skip-gradient window, tile at x0 = 0
   const float gs = p.gate_slope;
   const f32x2 slope2 = f32x2{p.slope, p.slope};
@@ -341,8 +363,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void conv3_bf16_k(Dev p) {
                   asm("v_max_f32 %0, %1, %2" : "=v"(vv[3]) : "v"(vv[3]), "v"(hi[1]));
                 }
               }
-              __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(vv[0], vv[1]), pack2(vv[2], vv[3])}, ors, vo[nt],
-                                                    so_z + (rr[i] * p.oH + x0[i] * p.oW) * 2, 0);
+              const u32x2 ov = u32x2{pack2(vv[0], vv[1]), pack2(vv[2], vv[3])};
+              const int so = so_z + (rr[i] * p.oH + x0[i] * p.oW) * 2;
+              if (!split || first[nt]) __builtin_amdgcn_raw_buffer_store_b64(ov, ors0, vo[nt], so, 0);     // (split: kernel-uniform)
+              else __builtin_amdgcn_raw_buffer_store_b64(ov, ors1, vo[nt], so, 0);
             }
           }
         }
@@ -390,7 +414,7 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
       const double step = 1000.0 + pairs * (2.0 * NSTEP * 16.0 * ((CO + 15) / 16) + 500.0);
       for (int RD = K + S; RD <= 8; ++RD) {
         if (knob_rd ? RD != knob_rd : RD != K + S) continue;
-        if (RD < K + S || RD * slot > LDS_MAX || (RD - K) * ndma > 62) continue;
+        if (RD < K + S || RD * slot > LDS_MAX || (RD - K) * ndma * (p.in1 != p.in0 ? 2 : 1) > 62) continue;
         for (int zsegs = 1; zsegs <= p.OD; ++zsegs) {
           if (knob_zs && zsegs != knob_zs) continue;
           const int zper = (p.OD + zsegs - 1) / zsegs, zs = (p.OD + zper - 1) / zper;
@@ -402,6 +426,7 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
             best = cost;
             p.TX = TX; p.TY = TY; p.nbx = nbx; p.nby = nby; p.zsegs = zs; p.zper = zper;
             p.RW = RW; p.PV = PV; p.ndma = ndma; p.slot_bytes = slot; p.RD = RD;
+            p.ndma_cnt = p.in1 != p.in0 ? 2 * ndma : ndma;
           }
         }
       }
@@ -459,25 +484,17 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int n
   Dev p{};
   if (!al16(i0) || !fits31(span(i0))) return TEM_EUNSUPPORTED;
   int CI = i0.C;
-  const u16 *p0 = U(i0.ptr), *p1 = p0;
-  int64_t ext0 = span(i0) * 2, ext1 = 0;
+  p.in0 = U(i0.ptr); p.in1 = p.in0;
+  p.in0_bytes = (uint32_t)(span(i0) * 2); p.in1_bytes = p.in0_bytes;
   p.i0N = (int)i0.sN; p.i0D = (int)i0.sD; p.i0H = (int)i0.sH; p.i0W = (int)i0.sW; p.C0 = i0.C;
   p.i1N = p.i0N; p.i1D = p.i0D; p.i1H = p.i0H; p.i1W = p.i0W;
   if (a->in1.ptr) {
     const tem_view &i1 = a->in1;
     if (i1.N != i0.N || i1.D != i0.D || i1.H != i0.H || i1.W != i0.W) return TEM_ESHAPE;
     if (!al16(i1) || !fits31(span(i1))) return TEM_EUNSUPPORTED;
-    p1 = U(i1.ptr); ext1 = span(i1) * 2;
+    p.in1 = U(i1.ptr); p.in1_bytes = (uint32_t)(span(i1) * 2);
     p.i1N = (int)i1.sN; p.i1D = (int)i1.sD; p.i1H = (int)i1.sH; p.i1W = (int)i1.sW;
     CI += i1.C;
-  }
-  {
-    // one buffer descriptor for both inputs of a concat: offsets relative to the lower base (31-bit byte offsets)
-    const u16 *lo = p0 < p1 ? p0 : p1;
-    const int64_t d0 = (const char *)p0 - (const char *)lo, d1 = (const char *)p1 - (const char *)lo;
-    const int64_t end = std::max(d0 + ext0, d1 + ext1);
-    if (end >= ((int64_t)1 << 31)) return TEM_EUNSUPPORTED;      // (offset 0x80000000 stays out of range: the zero fill)
-    p.inb = lo; p.off0 = (int)d0; p.off1 = (int)d1; p.in_bytes = (uint32_t)end;
   }
   p.D = i0.D; p.H = i0.H; p.W = i0.W; p.P = a->pd;
   p.w = U(a->w); p.flip = a->w_layout == TEM_W_FLIP_CO_CI;
@@ -485,21 +502,15 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int n
   p.oN = (int)o0.sN; p.oD = (int)o0.sD; p.oH = (int)o0.sH; p.oW = (int)o0.sW;
   p.CO0 = o0.C;
   int CO = o0.C;
-  {
-    const char *q0 = (const char *)o0.ptr, *q1 = q0;
-    int64_t e0 = span(o0) * 2, e1 = 0;
-    if (a->out1.ptr) {
-      const tem_view &o1 = a->out1;
-      if (o1.N != o0.N || o1.D != o0.D || o1.H != o0.H || o1.W != o0.W) return TEM_ESHAPE;
-      if (!al8(o1) || !fits31(span(o1))) return TEM_EUNSUPPORTED;
-      if (o1.sN != o0.sN || o1.sD != o0.sD || o1.sH != o0.sH || o1.sW != o0.sW) return TEM_EUNSUPPORTED;    // one scalar offset for both
-      q1 = (const char *)o1.ptr; e1 = span(o1) * 2;
-      CO += o1.C;
-    }
-    const char *lo = q0 < q1 ? q0 : q1;
-    const int64_t end = std::max((q0 - lo) + e0, (q1 - lo) + e1);
-    if (end >= ((int64_t)1 << 31)) return TEM_EUNSUPPORTED;
-    p.outb = (u16 *)lo; p.oo0 = (int)(q0 - lo); p.oo1 = (int)(q1 - lo); p.out_bytes = (uint32_t)end;
+  p.out0 = const_cast<u16 *>(U(o0.ptr)); p.out1 = p.out0;
+  p.out0_bytes = (uint32_t)(span(o0) * 2); p.out1_bytes = p.out0_bytes;
+  if (a->out1.ptr) {
+    const tem_view &o1 = a->out1;
+    if (o1.N != o0.N || o1.D != o0.D || o1.H != o0.H || o1.W != o0.W) return TEM_ESHAPE;
+    if (!al8(o1) || !fits31(span(o1))) return TEM_EUNSUPPORTED;
+    if (o1.sN != o0.sN || o1.sD != o0.sD || o1.sH != o0.sH || o1.sW != o0.sW) return TEM_EUNSUPPORTED;    // one scalar offset for both
+    p.out1 = const_cast<u16 *>(U(o1.ptr)); p.out1_bytes = (uint32_t)(span(o1) * 2);
+    CO += o1.C;
   }
   p.OD = o0.D; p.OH = o0.H; p.OW = o0.W;
   {
