@@ -178,6 +178,8 @@ class _CompiledStep:
         # LDS-bound kernels only steal CUs from the dependent chains; again in round 2 with GPU_MAX_HW_QUEUES=8, so
         # that no two streams share a hardware queue: 9.35 vs 8.52 ms/step) and HIP stream priorities for the
         # chains (17.9 ms/step).
+        # (round 3, rejected: only the LAST sweeps' kernel gradients on the discriminators' streams, idle by then -- 7.416 vs 7.418
+        # ms/step: two generator chains already fill the chip in that phase)
         # (also measured and rejected: starting the F chain a few layers behind the G chain so that one chain's
         # full-resolution layers meet the other's 27^3..60^3 layers -- 9.74-9.77 vs 9.73 ms/step)
         main += casts + [("record", "cast")] + [flips["g"]] + L_(f_g1) + [("record", "fake_y")] + L_(f_g3) + [("wait", "fake_x")] + L_(f_g2)
