@@ -46,8 +46,10 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
   constexpr int NTAP = K * K * K, ROWS = NTAP * CI, MT = (ROWS + 15) / 16, NT = (CO + 15) / 16;
   constexpr int WPN = 4 / NT;                              // waves per n-tile
   constexpr int TPW = (MTG + WPN - 1) / WPN;               // accumulator tiles per wave
-  constexpr int PITCH = CI >= 8 ? CI + 4 : 1;              // X voxel pitch (bf16 elements; 8-byte aligned)
-  constexpr int GP = CO + 4;                               // G voxel pitch
+  // voxel pitches (bf16 elements): measured (tests/tools/lds_tr_probe.hip) the transposing read streams 171 B/clk/CU at voxel
+  // pitches up to 32 bytes and 117 beyond -- the 8-byte pad of round 2 (40 bytes at 16 channels) cost a third of the rate
+  constexpr int PITCH = CI >= 8 ? (CI <= 16 ? CI : CI + 4) : 1;
+  constexpr int GP = CO <= 16 ? CO : CO + 4;
   constexpr int CPX = CI >= 8 ? CI / 8 : 1, CPG = CO / 8;  // 16-byte chunks per voxel
   static_assert(CO % 8 == 0 && (CI == 1 || CI % 8 == 0) && 4 % NT == 0, "channel counts");
   extern __shared__ __attribute__((aligned(16))) u16 lds[];
@@ -217,7 +219,7 @@ static thread_local int g_name_len = 0;
 template <int CI, int CO, int K, int S, int PFX, int PFG, int MTG>
 int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   constexpr int NTAP = K * K * K, MT = (NTAP * CI + 15) / 16;
-  constexpr int PITCH = CI >= 8 ? CI + 4 : 1, GP = CO + 4, CPX = CI >= 8 ? CI / 8 : 1, CPG = CO / 8;
+  constexpr int PITCH = CI >= 8 ? (CI <= 16 ? CI : CI + 4) : 1, GP = CO <= 16 ? CO : CO + 4, CPX = CI >= 8 ? CI / 8 : 1, CPG = CO / 8;
   p.OWp = (p.OW + 15) & ~15;
   p.colsR = (p.OW - 1) * S + K;
   p.colsA = (p.OWp - 1) * S + K + 4;                      // the last k-block reads up to OWp voxels (+ C_in == 1: 4-voxel reads)
