@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void conv_bf16_k(Dev p) {
   constexpr int NTAP = K * K * K, KTOT = NTAP * CI, NSTEP = (KTOT + 31) / 32, NT = (CO + 15) / 16;
   constexpr int WPN = NT >= 4 ? 1 : 4 / NT;                // waves per n-tile
   constexpr int NTW = NT >= 4 ? NT / 4 : 1;               // n-tiles per wave (C_out 64 would need 1; kept general)
-  constexpr int PITCH = CI >= 8 ? CI + 8 : 1;             // LDS voxel pitch in bf16 elements
+  constexpr int PITCH = CI >= 8 ? CI : 1;                 // LDS voxel pitch in bf16 elements (un-padded: lds_b128_probe3.hip)
   constexpr int CPV = CI >= 8 ? CI / 8 : 1;               // 16-byte chunks per voxel
   constexpr int TPITCH = 20;
   static_assert(CI == 1 || CI % 8 == 0, "C_in 1 or a multiple of 8");
@@ -356,7 +356,7 @@ static thread_local int g_name_len = 0;
 template <int CI, int CO, int K, int S, int PF, bool BLDS>
 int run(Dev p, int N, hipStream_t st, bool dry) {
   constexpr int NTAP = K * K * K, NSTEP = (NTAP * CI + 31) / 32, NT = (CO + 15) / 16;
-  constexpr int PITCH = CI >= 8 ? CI + 8 : 1, CPV = CI >= 8 ? CI / 8 : 1;
+  constexpr int PITCH = CI >= 8 ? CI : 1, CPV = CI >= 8 ? CI / 8 : 1;
   constexpr size_t B_BYTES = BLDS ? (size_t)NSTEP * NT * 64 * 16 : 0;
   constexpr size_t TAB_BYTES = (CI == 1 ? 32 : (BLDS ? 1 : 2) * ((NSTEP * 4 + 3) & ~3)) * 4;
   constexpr size_t FIXED = B_BYTES + TAB_BYTES + 4 * 16 * 20 * 4;
