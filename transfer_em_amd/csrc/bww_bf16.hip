@@ -15,6 +15,7 @@
 #include "tem_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 int tem_bww_c1_bf16_try(const tem_bww_args *a, hipStream_t st, bool dry, int *nslab_out, char *name, int name_len);
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
 
   // ---- this wave's accumulator tiles: n-tile fixed, m-tiles grp*MTG + (wave/NT) + j*WPN
   const int nt = wave % NT;
-  int aconst[TPW];
+  int aconst[TPW], adz[TPW];                               // fragment offset inside a plane, z tap of the lane's rows
   f32x4 acc[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
@@ -84,11 +85,13 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
       const int m0 = min(16 * mt + 4 * pq, ROWS - 4);                   // this lane addresses rows m0..m0+3 (4 channels of one tap)
       const int tap = m0 / CI, ci0 = m0 - tap * CI;
       const int dz = tap / (K * K), rem = tap - dz * (K * K), dy = rem / K, dx = rem - dy * K;
-      aconst[j] = ((dz * p.rows + dy) * p.colsA + dx) * PITCH + ci0 + (4 * g4 + q) * S * PITCH;
+      adz[j] = dz;
+      aconst[j] = (dy * p.colsA + dx) * PITCH + ci0 + (4 * g4 + q) * S * PITCH;
     } else {
       const int tap = min(16 * mt + m, NTAP - 1);                       // row m of the tile = one tap
       const int dz = tap / (K * K), rem = tap - dz * (K * K), dy = rem / K, dx = rem - dy * K;
-      aconst[j] = (dz * p.rows + dy) * p.colsA + dx + 4 * g4;
+      adz[j] = dz;
+      aconst[j] = dy * p.colsA + dx + 4 * g4;
     }
     acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -96,84 +99,108 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
 
   const int iy0 = oy0 * S - p.P;
   const int nk = p.OWp >> 4;
-  for (int oz = oz0; oz < oz1; ++oz) {
-    __syncthreads();                                         // zero fill done / previous plane's readers done
-    // ---- X patch (K planes) and G rows of this output plane: all loads first, then the LDS writes
-    {
-      const int iz0 = oz * S - p.P;
+  // The K input planes of an output plane live in a RING of K LDS slots (plane counter c -> slot c % K): only the S planes that
+  // are new to an output plane are fetched (round 2 re-loaded all K every time: 3-4x the bytes through L2 and the loader, which
+  // -- not MFMAs or LDS reads -- was the kernel's time).  One pass of the loader = one plane; all of a pass's loads are issued
+  // before its LDS writes.
+  constexpr int PF1 = (PFX + 2) / 3;                         // loader chunks per thread and PLANE
+  typedef typename std::conditional<(CI >= 8), uint4, u16>::type xchunk;
+  auto issue_x = [&](int c, xchunk (&pf)[PF1]) {             // global loads of plane counter c: input plane (oz0 * S - P) + c
+    const int iz = oz0 * S - p.P + c;
+#pragma unroll
+    for (int i = 0; i < PF1; ++i) {
+      const int id = tid + i * 256;
       if constexpr (CI >= 8) {
-        const int totalX = K * p.rows * p.colsR * CPX;
-        uint4 pf[PFX];
+        const int totalX = p.rows * p.colsR * CPX;
+        const int vox = id / CPX, c8 = (id - vox * CPX) * 8;
+        const int r = fdiv(vox, p.colsR, p.magicColsR), cx = vox - r * p.colsR;
+        const int iy = iy0 + r, ix = cx - p.P;
+        const bool ok = id < totalX && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const u16 *src = c8 < p.C0 ? p.in0 + (n * p.i0N + iz * p.i0D + iy * p.i0H + ix * p.i0W + c8)
+                                   : p.in1 + (n * p.i1N + iz * p.i1D + iy * p.i1H + ix * p.i1W + (c8 - p.C0));
+        pf[i] = ok ? *reinterpret_cast<const uint4 *>(src) : make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        const int totalX = p.rows * p.colsR;
+        const int r = fdiv(id, p.colsR, p.magicColsR), cx = id - r * p.colsR;
+        const int iy = iy0 + r, ix = cx - p.P;
+        const bool ok = id < totalX && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        pf[i] = ok ? p.in0[n * p.i0N + iz * p.i0D + iy * p.i0H + ix * p.i0W] : (u16)0;
+      }
+    }
+  };
+  auto commit_x = [&](int c, const xchunk (&pf)[PF1]) {      // ... into ring slot c % K
+    u16 *dstp = Xs + (c % K) * planeA * PITCH;
 #pragma unroll
-        for (int i = 0; i < PFX; ++i) {
-          const int id = tid + i * 256;
-          const int vox = id / CPX, c = (id - vox * CPX) * 8;
-          const int pl = fdiv(vox, p.rows * p.colsR, p.magicPlaneR), r2 = vox - pl * (p.rows * p.colsR);
-          const int r = fdiv(r2, p.colsR, p.magicColsR), cx = r2 - r * p.colsR;
-          const int iz = iz0 + pl, iy = iy0 + r, ix = cx - p.P;
-          const bool ok = id < totalX && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-          const u16 *src = c < p.C0 ? p.in0 + (n * p.i0N + iz * p.i0D + iy * p.i0H + ix * p.i0W + c)
-                                    : p.in1 + (n * p.i1N + iz * p.i1D + iy * p.i1H + ix * p.i1W + (c - p.C0));
-          pf[i] = ok ? *reinterpret_cast<const uint4 *>(src) : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int i = 0; i < PFX; ++i) {
-          const int id = tid + i * 256;
-          if (id < totalX) {
-            const int vox = id / CPX, c = (id - vox * CPX) * 8;
-            const int pl = fdiv(vox, p.rows * p.colsR, p.magicPlaneR), r2 = vox - pl * (p.rows * p.colsR);
-            const int r = fdiv(r2, p.colsR, p.magicColsR), cx = r2 - r * p.colsR;
-            u16 *d = Xs + ((pl * p.rows + r) * p.colsA + cx) * PITCH + c;       // 8-byte aligned
-            *reinterpret_cast<uint2 *>(d) = make_uint2(pf[i].x, pf[i].y);
-            *reinterpret_cast<uint2 *>(d + 4) = make_uint2(pf[i].z, pf[i].w);
-          }
+    for (int i = 0; i < PF1; ++i) {
+      const int id = tid + i * 256;
+      if constexpr (CI >= 8) {
+        if (id < p.rows * p.colsR * CPX) {
+          const int vox = id / CPX, c8 = (id - vox * CPX) * 8;
+          const int r = fdiv(vox, p.colsR, p.magicColsR), cx = vox - r * p.colsR;
+          u16 *d = dstp + (r * p.colsA + cx) * PITCH + c8;       // 8-byte aligned
+          *reinterpret_cast<uint2 *>(d) = make_uint2(pf[i].x, pf[i].y);
+          *reinterpret_cast<uint2 *>(d + 4) = make_uint2(pf[i].z, pf[i].w);
         }
       } else {
-        const int totalX = K * p.rows * p.colsR;
-        u16 pf[PFX];
-#pragma unroll
-        for (int i = 0; i < PFX; ++i) {
-          const int id = tid + i * 256;
-          const int pl = fdiv(id, p.rows * p.colsR, p.magicPlaneR), r2 = id - pl * (p.rows * p.colsR);
-          const int r = fdiv(r2, p.colsR, p.magicColsR), cx = r2 - r * p.colsR;
-          const int iz = iz0 + pl, iy = iy0 + r, ix = cx - p.P;
-          const bool ok = id < totalX && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-          pf[i] = ok ? p.in0[n * p.i0N + iz * p.i0D + iy * p.i0H + ix * p.i0W] : (u16)0;
-        }
-#pragma unroll
-        for (int i = 0; i < PFX; ++i) {
-          const int id = tid + i * 256;
-          if (id < totalX) {
-            const int pl = fdiv(id, p.rows * p.colsR, p.magicPlaneR), r2 = id - pl * (p.rows * p.colsR);
-            const int r = fdiv(r2, p.colsR, p.magicColsR), cx = r2 - r * p.colsR;
-            Xs[(pl * p.rows + r) * p.colsA + cx] = pf[i];
-          }
-        }
-      }
-      const int totalG = TYr * p.OW * CPG;
-      uint4 pg[PFG];
-#pragma unroll
-      for (int i = 0; i < PFG; ++i) {
-        const int id = tid + i * 256;
-        const int vox = id / CPG, c = (id - vox * CPG) * 8;
-        const int r = fdiv(vox, p.OW, p.magicOW), x = vox - r * p.OW;
-        pg[i] = id < totalG ? *reinterpret_cast<const uint4 *>(p.g + (n * p.gN + oz * p.gD + (oy0 + r) * p.gH + x * p.gW + c))
-                            : make_uint4(0u, 0u, 0u, 0u);
-      }
-#pragma unroll
-      for (int i = 0; i < PFG; ++i) {
-        const int id = tid + i * 256;
-        if (id < totalG) {
-          const int vox = id / CPG, c = (id - vox * CPG) * 8;
-          const int r = fdiv(vox, p.OW, p.magicOW), x = vox - r * p.OW;
-          u16 *d = Gs + (r * p.OWp + x) * GP + c;
-          *reinterpret_cast<uint2 *>(d) = make_uint2(pg[i].x, pg[i].y);
-          *reinterpret_cast<uint2 *>(d + 4) = make_uint2(pg[i].z, pg[i].w);
+        if (id < p.rows * p.colsR) {
+          const int r = fdiv(id, p.colsR, p.magicColsR), cx = id - r * p.colsR;
+          dstp[r * p.colsA + cx] = pf[i];
         }
       }
     }
-    __syncthreads();
+  };
+  auto issue_g = [&](int oz, uint4 (&pg)[PFG]) {
+    const int totalG = TYr * p.OW * CPG;
+#pragma unroll
+    for (int i = 0; i < PFG; ++i) {
+      const int id = tid + i * 256;
+      const int vox = id / CPG, c = (id - vox * CPG) * 8;
+      const int r = fdiv(vox, p.OW, p.magicOW), x = vox - r * p.OW;
+      pg[i] = id < totalG ? *reinterpret_cast<const uint4 *>(p.g + (n * p.gN + oz * p.gD + (oy0 + r) * p.gH + x * p.gW + c))
+                          : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto commit_g = [&](const uint4 (&pg)[PFG]) {
+    const int totalG = TYr * p.OW * CPG;
+#pragma unroll
+    for (int i = 0; i < PFG; ++i) {
+      const int id = tid + i * 256;
+      if (id < totalG) {
+        const int vox = id / CPG, c = (id - vox * CPG) * 8;
+        const int r = fdiv(vox, p.OW, p.magicOW), x = vox - r * p.OW;
+        u16 *d = Gs + (r * p.OWp + x) * GP + c;
+        *reinterpret_cast<uint2 *>(d) = make_uint2(pg[i].x, pg[i].y);
+        *reinterpret_cast<uint2 *>(d + 4) = make_uint2(pg[i].z, pg[i].w);
+      }
+    }
+  };
+  // prologue: the K planes and the G rows of the first output plane
+  {
+    xchunk pf[PF1];
+    uint4 pg[PFG];
+    __syncthreads();                                         // zero fill done
+    for (int c = 0; c < K; ++c) { issue_x(c, pf); commit_x(c, pf); }
+    issue_g(oz0, pg); commit_g(pg);
+  }
+  for (int oz = oz0; oz < oz1; ++oz) {
+    __syncthreads();                                         // this plane's image is complete
+    // the S new planes and the G rows of the NEXT output plane fly into registers under this plane's matrix work
+    const bool more = oz + 1 < oz1;
+    xchunk nf[S][PF1];
+    uint4 ng[PFG];
+    const int cn = (oz + 1 - oz0) * S + K - S;               // first new plane counter of the next output plane
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) issue_x(cn + i, nf[i]);
+      issue_g(oz + 1, ng);
+    }
     // ---- k-blocks of 16 voxels along x, row by row
+    int xsl[TPW];                                            // + the ring slot of the lane's z tap
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) xsl[j] = aconst[j] + (((oz - oz0) * S + adz[j]) % K) * planeA * PITCH;
+    // (measured and rejected: all fragments of a k-block requested before its first MFMA plus the next k-block's ahead of them, two
+    // register sets in turn -- 40 -> 43 us at 16 -> 16, 25 -> 35 at 16 -> 32 k4 s2; with a branch around the second MFMA group hipcc
+    // shuttles every accumulator between AGPRs and VGPRs per MFMA: 53 us)
     for (int r = 0; r < TYr; ++r) {
       const u16 *xr = Xs + r * S * p.colsA * PITCH;
       const u16 *gr = Gs + r * p.OWp * GP + bconst;
@@ -183,15 +210,21 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
           if constexpr (CI >= 8) {
-            afrag[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(xr + aconst[j] + kb * 16 * S * PITCH));
+            afrag[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(xr + xsl[j] + kb * 16 * S * PITCH));
           } else {
-            const u16 *s = xr + aconst[j] + kb * 16;
+            const u16 *s = xr + xsl[j] + kb * 16;
             afrag[j] = s16x4{(short)s[0], (short)s[1], (short)s[2], (short)s[3]};
           }
         }
 #pragma unroll
         for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afrag[j], bfrag, acc[j], 0, 0, 0);
       }
+    }
+    if (more) {
+      __syncthreads();                                       // every wave is done with the S oldest planes and the G rows
+#pragma unroll
+      for (int i = 0; i < S; ++i) commit_x(cn + i, nf[i]);
+      commit_g(ng);
     }
   }
 
@@ -230,7 +263,7 @@ int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
     const size_t xel = (((size_t)K * rows * p.colsA * PITCH) + 7) & ~(size_t)7, gel = (size_t)ty * p.OWp * GP + 16;
     const size_t bytes = ((xel + gel) * 2 + 15) & ~(size_t)15;
     // two workgroups per CU (<= 72 KB each) where the patch allows; a single row band may take up to 120 KB
-    if ((size_t)K * rows * p.colsR * CPX > (size_t)PFX * 256 || (size_t)ty * p.OW * CPG > (size_t)PFG * 256 ||
+    if ((size_t)rows * p.colsR * CPX > (size_t)((PFX + 2) / 3) * 256 || (size_t)ty * p.OW * CPG > (size_t)PFG * 256 ||
         bytes > (ty == 1 ? 120 : 72) * 1024) break;
     TY = ty; lds_bytes = bytes;
   }
