@@ -271,7 +271,11 @@ int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   p.TY = TY; p.rows = (TY - 1) * S + K;
   p.nband = (p.OH + TY - 1) / TY;
   const int cols = N * p.nband;
-  int want = max_slabs < 512 ? max_slabs : 512;            // ~2 workgroups per CU (320 measured slower: 3.46 vs 2.85 ms/step)
+  // ~1 workgroup per CU: with the plane ring and the register prefetch a workgroup overlaps its own fetches, and every workgroup
+  // costs a slab (written here, read again by reduce_multi_k) -- bf16 step by workgroup budget: 512: 4.64 ms, 384: 4.47, 256: 4.38,
+  // 192: 4.34, 128: 4.49, 96: 4.77 (round 2, before the ring: 320 measured slower than 512)
+  const int want_knob = tem_env_int("TEM_BWWH_WANT", 256);
+  int want = max_slabs < want_knob ? max_slabs : want_knob;
   int zsegs = want / cols;
   if (zsegs < 1) zsegs = 1;
   if (zsegs > p.OD) zsegs = p.OD;
