@@ -1,7 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from transfer_em_amd.cgan import EM2EM
-m = EM2EM(132, "sl", checkpoint_root="/tmp/sl_ck")
+m = EM2EM(132, "sl", checkpoint_root="/tmp/sl_ck", precision=(sys.argv[1] if len(sys.argv) > 1 else "fp32"))
 x = torch.randn(1, 132, 132, 132, 1, device="cuda")
 m.train_step(x, x); torch.cuda.synchronize()
 st = m._compiled(1)

@@ -274,7 +274,10 @@ int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   // ~1 workgroup per CU: with the plane ring and the register prefetch a workgroup overlaps its own fetches, and every workgroup
   // costs a slab (written here, read again by reduce_multi_k) -- bf16 step by workgroup budget: 512: 4.64 ms, 384: 4.47, 256: 4.38,
   // 192: 4.34, 128: 4.49, 96: 4.77 (round 2, before the ring: 320 measured slower than 512)
-  const int want_knob = tem_env_int("TEM_BWWH_WANT", 256);
+  constexpr int NGRP = (MT + MTG - 1) / MTG;
+  // (the budget counts WORKGROUPS: a layer whose rows are split over NGRP row groups gets 256 / NGRP slabs -- the 32 -> 32
+  // 4x4x4 layer of the discriminators wrote 200 slabs of 262 KB per call, 52 MB against 4 MB of operands: 4.35 -> 4.25 ms)
+  const int want_knob = tem_env_int("TEM_BWWH_WANT", 256) / NGRP;
   int want = max_slabs < want_knob ? max_slabs : want_knob;
   int zsegs = want / cols;
   if (zsegs < 1) zsegs = 1;
@@ -298,7 +301,6 @@ int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  constexpr int NGRP = (MT + MTG - 1) / MTG;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, NGRP), dim3(256), lds_bytes, st, p);
   TEM_CHECK_LAUNCH();
   return TEM_OK;

@@ -63,7 +63,7 @@ struct Dev {
 // NCLS * 2 C_in VGPRs) -- 4 for C_in 8, 2 (both r_y of one r_z) for C_in 16, 1 for C_in 32
 template <int CI, int CO, int PF, int NCLS>
 __global__ __launch_bounds__(256) void convT_bf16_k(Dev p, const u16 *__restrict__ wgt) {
-  constexpr int CIP = CI + 8;                     // LDS voxel pitch (bf16 elements): 2 C_in + 16 bytes, conflict-free b128
+  constexpr int CIP = CI;                         // LDS voxel pitch (bf16 elements): the plain channels-last image (b128 fragment reads are conflict-free, lds_b128_probe; the 16-byte pad of round 2 cost ~8 %)
   constexpr int NT = 2 * CO / 16;                 // n-tiles over the columns (r_x, co)
   constexpr int WPN = 4 / NT;                     // waves per n-tile (tile subsets)
   constexpr int NSTEP = 8 * CI / 32;              // k-steps of 32: k = (tap8, ci), a lane's 8 k-values = 8 channels of one tap
@@ -277,7 +277,7 @@ static int floordiv2(int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }
 
 template <int CI, int CO, int PF, int NCLS>
 int run(Dev p, int N, const u16 *w, hipStream_t st, bool dry) {
-  constexpr int CIP = CI + 8, CPV = CI / 8;
+  constexpr int CIP = CI, CPV = CI / 8;
   // o + P = 2Q + r  =>  Q in [floor(P/2), floor((O-1+P)/2)]
   p.Qlo_x = floordiv2(p.P); p.nQx = floordiv2(p.OW - 1 + p.P) - p.Qlo_x + 1;
   p.Qlo_y = floordiv2(p.P); p.nQy = floordiv2(p.OH - 1 + p.P) - p.Qlo_y + 1;
