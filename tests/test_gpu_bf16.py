@@ -61,7 +61,36 @@ def test_conv_bf16_forward(H, oracle_lib, CI, CO, k, s, pad, n):
                            bias=torch.from_numpy(bias).cuda() if bias is not None else None)
     H.run([launch])
     marching = CI >= 8 and CO >= 8 and ((k == 3 and s == 1) or (k == 4 and s == 2 and CI <= 16))
-    assert launch.meta["kernel"].startswith("conv3_bf16_k" if marching else "conv_bf16_k")
+    c1out = CO == 1 and k == 3 and CI in (8, 16)
+    assert launch.meta["kernel"].startswith("c1out_h_k" if c1out else "conv3_bf16_k" if marching else "conv_bf16_k")
+    assert rel_err(out.float().cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("CI", [8, 16])
+def test_conv_bf16_one_output_channel(H, oracle_lib, CI):
+    """c1out_h_k: the one-output-channel 3x3x3 layers with bf16 tensors (fragments straight from global memory, one bf16
+    MFMA per 16 voxels and n-tile, fp32 shifted sum through LDS): forward with bias + LeakyReLU on a ragged batch-2 volume
+    (patches of 16 x 16 columns with partial edges, two z-runs), and the input-gradient form of a 1 -> CI layer (flipped
+    taps, padding 2, LeakyReLU' gate)."""
+    rng = np.random.default_rng(100 + CI)
+    x = rb(rnd(rng, 2, 21, 23, 37, CI))
+    w = rb(rnd(rng, 3, 3, 3, CI, 1) * 0.2)
+    bias = rnd(rng, 1)
+    ref = oracle_lib.leaky_relu(oracle_lib.conv_fwd(x, w, 1, 0, bias))
+    out = torch.empty(ref.shape, dtype=torch.bfloat16, device="cuda")
+    launch = H.conv_launch("t", devb(x), pack(w), out, 3, 1, 0, slope=0.3, bias=torch.from_numpy(bias).cuda())
+    H.run([launch])
+    assert launch.meta["kernel"].startswith("c1out_h_k"), launch.meta["kernel"]
+    assert rel_err(out.float().cpu().numpy(), ref) < TOL
+    g = rb(rnd(rng, 2, 9, 18, 31, CI))
+    wf = rb(rnd(rng, 3, 3, 3, 1, CI) * 0.3)
+    shape = (2, 11, 20, 33, 1)
+    saved = rb(rnd(rng, *shape))
+    ref = oracle_lib.leaky_relu_grad_from_out(oracle_lib.conv_bwd_data(g, wf, shape), saved)
+    out = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+    launch = H.conv_launch("t", devb(g), devb(wf.reshape(-1)), out, 3, 1, 2, layout=H.TEM_W_FLIP_CO_CI, gate=devb(saved))
+    H.run([launch])
+    assert launch.meta["kernel"].startswith("c1out_h_k"), launch.meta["kernel"]
     assert rel_err(out.float().cpu().numpy(), ref) < TOL
 
 

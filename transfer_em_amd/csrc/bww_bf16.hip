@@ -277,7 +277,8 @@ int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   constexpr int NGRP = (MT + MTG - 1) / MTG;
   // (the budget counts WORKGROUPS: a layer whose rows are split over NGRP row groups gets 256 / NGRP slabs -- the 32 -> 32
   // 4x4x4 layer of the discriminators wrote 200 slabs of 262 KB per call, 52 MB against 4 MB of operands: 4.35 -> 4.25 ms)
-  const int want_knob = tem_env_int("TEM_BWWH_WANT", 256) / NGRP;
+  const bool small_slab = NTAP * CI * CO * 4 <= tem_env_int("TEM_BWWH_SMALLKB", 32) * 1024;
+  const int want_knob = (small_slab ? tem_env_int("TEM_BWWH_SMALL", 256) : tem_env_int("TEM_BWWH_WANT", 256)) / NGRP;
   int want = max_slabs < want_knob ? max_slabs : want_knob;
   int zsegs = want / cols;
   if (zsegs < 1) zsegs = 1;

@@ -172,6 +172,142 @@ __global__ __launch_bounds__(256, 2) void c1out_mfma_k(Dev p) {
   }
 }
 
+// ---- bf16 mode (conv_bf16.hip tries this for the one-output-channel 3x3x3 layers): the same march with bf16 fragments.
+// One v_mfma_f32_16x16x16_bf16 spans all 16 input channels (8: the lane groups 2 and 3 load nothing and multiply zeros), so a
+// 16-voxel tile costs one 8-byte load per lane (512 contiguous bytes per wave instruction) and two MFMAs instead of eight:
+// in fp32 the kernel is bound by 48 MFMAs of 32 cycles per plane and wave, here by the shifted sum and HBM.  P, the three
+// accumulators and the epilogue stay fp32; input, gate and output are bf16, the kernel is the packed bf16 copy [tap][ci].
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+
+struct DevH {
+  const u16 *in;
+  int32_t iN, iD, iH, iW, D, H, W, in_bytes;
+  const u16 *w;
+  u16 *out;
+  int32_t oN, oD, oH, oW, OD, OH, OW;
+  int32_t P;
+  int32_t ntx, nty, zsegs, zper;
+  float slope;
+  const u16 *gate; int32_t gN, gD, gH, gW; float gate_slope;
+  const float *bias;
+};
+
+template <int CI, bool FLIP>
+__global__ __launch_bounds__(256, 2) void c1out_h_k(DevH p) {
+  static_assert(CI == 16 || CI == 8, "one 8-byte load per lane and voxel");
+  extern __shared__ __attribute__((aligned(16))) float P_[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+
+  int b = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int zseg = b % p.zsegs; b /= p.zsegs;
+  const int txi = b % p.ntx; b /= p.ntx;
+  const int tyi = b % p.nty;
+  const int n = b / p.nty;
+  const int ox0 = txi * TX, oy0 = tyi * TY;
+  const int oz0 = zseg * p.zper, oz1 = min(p.OD, oz0 + p.zper);
+  const int nplanes = oz1 - oz0 + 2;
+  const int iz0 = oz0 - p.P;
+
+  // ---- B fragments: column t = 16 nt + m (tap), the lane's k = channels 4 kq .. 4 kq + 3
+  s16x4 B[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int t = 16 * nt + m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      B[nt][i] = (t < 27 && 4 * kq + i < CI) ? (short)p.w[(FLIP ? 26 - t : t) * CI + 4 * kq + i] : (short)0;
+  }
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
+  int goff[NTW];                                     // byte offset inside plane iz = 0 (or OOB: outside the image / the patch)
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int v = (wave + 4 * i) * 16 + m;
+    const int r = v / COLS, c = v - r * COLS;
+    const int iy = oy0 - p.P + r, ix = ox0 - p.P + c;
+    const bool ok = v < PV && 4 * kq < CI && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    goff[i] = ok ? (n * p.iN + iy * p.iH + ix * p.iW + 4 * kq) * 2 : OOB;
+  }
+  auto load_plane = [&](s16x4 (&a)[NTW], int iz) {
+    const bool zin = (unsigned)iz < (unsigned)p.D;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int off = (zin && goff[i] != OOB) ? goff[i] + iz * p.iD * 2 : OOB;
+      a[i] = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(xrs, off, 0, 0));
+    }
+  };
+
+  const int ty = tid >> 4, tx = tid & 15;
+  const int ox = ox0 + tx, oy = oy0 + ty;
+  const bool owner = ox < p.OW && oy < p.OH;
+  const float *pbase = P_ + (ty * COLS + tx) * PITCH;
+  const int ooff = n * p.oN + oy * p.oH + ox * p.oW;
+  const int gbase = n * p.gN + oy * p.gH + ox * p.gW;
+
+  float acc[3] = {0.f, 0.f, 0.f};
+  auto p_phase = [&](const s16x4 (&a)[NTW], int buf) {
+    float *const Pb = P_ + buf * PBUF;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      if (wave + 4 * i < NTILE) {                            // wave-uniform
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], B[0], z, 0, 0, 0);
+        const f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], B[1], z, 0, 0, 0);
+        float *d = Pb + ((wave + 4 * i) * 16 + 4 * kq) * PITCH + m;          // rows 4 kq + r of the tile, column m
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d[r * PITCH] = c0[r];
+          if (m < 11) d[r * PITCH + 16] = c1[r];
+        }
+      }
+    }
+  };
+  s16x4 a0[NTW], a1[NTW];
+  load_plane(a0, iz0);
+  load_plane(a1, nplanes > 1 ? iz0 + 1 : -1);
+  p_phase(a0, 0);
+  auto step = [&](s16x4 (&anow)[NTW], s16x4 (&aload)[NTW], int j, int r3) {
+    __syncthreads();                                         // P(j) is complete; nobody still reads the buffer P(j + 1) goes to
+    const int ozf = oz0 + j - 2;                             // the output plane this step completes
+    float gv = 1.f;
+    if (p.gate && j >= 2 && owner) gv = __uint_as_float((uint32_t)p.gate[gbase + ozf * p.gD] << 16);
+    if (j + 1 < nplanes) p_phase(anow, (j + 1) & 1);         // block-uniform
+    load_plane(aload, j + 2 < nplanes ? iz0 + j + 2 : -1);   // (past the run: out of range, moves no data)
+    const float *pb = pbase + (j & 1) * PBUF;
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) {
+      float s = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) s += pb[(dy * COLS + dx) * PITCH + (dz * 3 + dy) * 3 + dx];
+      acc[(r3 + 3 - dz) % 3] += s;
+    }
+    if (j >= 2 && owner) {                                   // output plane j - 2 is complete
+      float v = acc[(r3 + 1) % 3];
+      if (p.bias) v += p.bias[0];
+      if (p.gate) v = gv > 0.f ? v : p.gate_slope * v;
+      if (p.slope != 1.f) v = v > 0.f ? v : p.slope * v;
+      p.out[ooff + ozf * p.oD] = __builtin_bit_cast(u16, (__bf16)v);           // round to nearest even
+    }
+    acc[(r3 + 1) % 3] = 0.f;
+  };
+  for (int j0 = 0; j0 < nplanes; j0 += 6) {
+#pragma unroll
+    for (int r6 = 0; r6 < 6; ++r6) {
+      const int j = j0 + r6;
+      if (j < nplanes) {                                     // block-uniform
+        if (r6 & 1) step(a0, a1, j, r6 % 3);
+        else step(a1, a0, j, r6 % 3);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host
 static bool fits32(const tem_view &v) {
   int64_t span = (int64_t)(v.N - 1) * v.sN + (int64_t)(v.D - 1) * v.sD + (int64_t)(v.H - 1) * v.sH +
@@ -249,6 +385,66 @@ static int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   return flip ? run<16, true>(p, N, st, dry) : run<16, false>(p, N, st, dry);     // g.f2 forward
 }
 
+
+template <int CI, bool FLIP>
+static int run_h(DevH p, int N, hipStream_t st, bool dry, char *name, int name_len) {
+  if (name) snprintf(name, name_len, "c1out_h_k<%d, %s>", CI, FLIP ? "true" : "false");
+  if (dry) return TEM_OK;
+  p.ntx = (p.OW + TX - 1) / TX; p.nty = (p.OH + TY - 1) / TY;
+  const int tiles = p.ntx * p.nty * N;
+  int zsegs = (512 + tiles - 1) / tiles;
+  if (zsegs < 1) zsegs = 1;
+  int zper = (p.OD + zsegs - 1) / zsegs;
+  if (zper < 8) zper = p.OD < 8 ? p.OD : 8;
+  p.zper = zper;
+  p.zsegs = (p.OD + zper - 1) / zper;
+  const size_t lds_bytes = (size_t)2 * PBUF * 4;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void *)c1out_h_k<CI, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  const int nblocks = p.zsegs * p.ntx * p.nty * N;
+  hipLaunchKernelGGL((c1out_h_k<CI, FLIP>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p);
+  TEM_CHECK_LAUNCH();
+  return TEM_OK;
+}
+
+// bf16 tensors behind the float* fields of tem_conv_args (strides in elements), `w` = the packed bf16 kernel [tap][ci]
+static int dispatch_h(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int name_len) {
+  const tem_view &i0 = a->in0, &o0 = a->out0;
+  if (a->in1.ptr || a->out1.ptr || o0.C != 1 || (i0.C != 16 && i0.C != 8)) return TEM_EUNSUPPORTED;
+  if (a->kd != 3 || a->kh != 3 || a->kw != 3 || a->sd != 1 || a->sh != 1 || a->sw != 1) return TEM_EUNSUPPORTED;
+  if (a->pd != a->ph || a->ph != a->pw) return TEM_EUNSUPPORTED;
+  if (a->ep.dropout || a->ep.add.ptr) return TEM_EUNSUPPORTED;
+  if (o0.N != i0.N) return TEM_ESHAPE;
+  if (!fits32(i0) || !fits32(o0)) return TEM_EUNSUPPORTED;
+  if (((uintptr_t)i0.ptr & 7) || i0.sW % 4 || i0.sH % 4 || i0.sD % 4 || i0.sN % 4) return TEM_EUNSUPPORTED;
+  auto U = [](const float *q) { return reinterpret_cast<const u16 *>(q); };
+  DevH p{};
+  p.in = U(i0.ptr); p.iN = (int)i0.sN; p.iD = (int)i0.sD; p.iH = (int)i0.sH; p.iW = (int)i0.sW;
+  p.D = i0.D; p.H = i0.H; p.W = i0.W;
+  p.in_bytes = (int)(((int64_t)(i0.N - 1) * i0.sN + (int64_t)(i0.D - 1) * i0.sD + (int64_t)(i0.H - 1) * i0.sH +
+                      (int64_t)(i0.W - 1) * i0.sW + i0.C) * 2);
+  p.w = U(a->w);
+  p.out = const_cast<u16 *>(U(o0.ptr)); p.oN = (int)o0.sN; p.oD = (int)o0.sD; p.oH = (int)o0.sH; p.oW = (int)o0.sW;
+  p.OD = o0.D; p.OH = o0.H; p.OW = o0.W;
+  p.P = a->pd;
+  p.slope = a->ep.slope; p.gate_slope = a->ep.gate_slope; p.bias = a->ep.bias;
+  if (a->ep.gate.ptr) {
+    const tem_view &g = a->ep.gate;
+    if (g.N != o0.N || g.D != o0.D || g.H != o0.H || g.W != o0.W || g.C < o0.C) return TEM_ESHAPE;
+    if (!fits32(g)) return TEM_EUNSUPPORTED;
+    p.gate = U(g.ptr); p.gN = (int)g.sN; p.gD = (int)g.sD; p.gH = (int)g.sH; p.gW = (int)g.sW;
+  }
+  const bool flip = a->w_layout == TEM_W_FLIP_CO_CI;
+  if (a->w_layout != TEM_W_TAP_CI_CO && !flip) return TEM_EUNSUPPORTED;
+  const int N = i0.N;
+  if (i0.C == 16) return flip ? run_h<16, true>(p, N, st, dry, name, name_len) : run_h<16, false>(p, N, st, dry, name, name_len);
+  return flip ? run_h<8, true>(p, N, st, dry, name, name_len) : run_h<8, false>(p, N, st, dry, name, name_len);
+}
+
 }  // namespace c1out
 
 // Called by tem_conv (dispatch.hip) ahead of the VALU stencil.
@@ -259,4 +455,9 @@ int tem_conv_c1out_describe(const tem_conv_args *a, char *buf, int len) {
   int rc = c1out::dispatch(a, nullptr, true);
   c1out::g_name = nullptr;
   return rc;
+}
+
+// bf16 mode (conv_bf16.hip tries this for the one-output-channel 3x3x3 layers)
+int tem_conv_c1out_bf16_try(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int name_len) {
+  return c1out::dispatch_h(a, st, dry, name, name_len);
 }

@@ -503,6 +503,7 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
 
 namespace conv3_bf16 { int dispatch(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int name_len); }
 int tem_conv_c1_bf16_try(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int name_len);     // stencil_c1.hip
+int tem_conv_c1out_bf16_try(const tem_conv_args *a, hipStream_t st, bool dry, char *name, int name_len);  // c1out_mfma.hip
 
 // bf16 mode: activations, gate / add views and the packed kernel are bf16 (the float* fields of tem_conv_args carry
 // bf16 pointers, strides in elements); slope / bias / dropout as in tem_conv.
@@ -511,6 +512,8 @@ extern "C" int tem_conv_bf16(const tem_conv_args *a, tem_stream_t stream) {
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->out0) || !a->w) return TEM_EINVAL;
   const int rc1 = tem_conv_c1_bf16_try(a, (hipStream_t)stream, false, nullptr, 0);    // one input channel, 3x3x3
   if (rc1 != TEM_EUNSUPPORTED) return rc1;
+  const int rc2 = tem_conv_c1out_bf16_try(a, (hipStream_t)stream, false, nullptr, 0); // one output channel, 3x3x3
+  if (rc2 != TEM_EUNSUPPORTED) return rc2;
   const int rc = conv3_bf16::dispatch(a, (hipStream_t)stream, false, nullptr, 0);     // 3x3x3 stride 1, 8..32 channels
   if (rc != TEM_EUNSUPPORTED) return rc;
   return conv_bf16::dispatch(a, (hipStream_t)stream, false);
@@ -520,6 +523,8 @@ extern "C" int tem_conv_bf16_describe(const tem_conv_args *a, char *buf, int32_t
   if (!a || !tem_view_ok(a->in0) || !tem_view_ok(a->out0) || !a->w) return TEM_EINVAL;
   const int rc1 = tem_conv_c1_bf16_try(a, nullptr, true, buf, len);
   if (rc1 != TEM_EUNSUPPORTED) return rc1;
+  const int rc2 = tem_conv_c1out_bf16_try(a, nullptr, true, buf, len);
+  if (rc2 != TEM_EUNSUPPORTED) return rc2;
   const int rc3 = conv3_bf16::dispatch(a, nullptr, true, buf, len);
   if (rc3 != TEM_EUNSUPPORTED) return rc3;
   conv_bf16::g_name = buf; conv_bf16::g_name_len = len;
