@@ -321,6 +321,42 @@ __global__ __launch_bounds__(256) void conv_bf16_k(Dev p) {
     const int b0 = a_base(t), b1 = a_base(two ? t2 : t);
     const Prep q0 = prep(t), q1 = prep(two ? t2 : t);
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!BLDS && CI == 32) {
+      // 32 input channels, kernel read from L2: k-step s IS tap s, so neither the patch offset nor the kernel offset needs the
+      // LDS table (a dependent LDS read in front of every gather and every kernel load), and the kernel fragments of 16 taps
+      // are requested in one go, one batch ahead of the matrix work.  [As a table-driven loop unrolled by 4 the 64 k-steps
+      // were 16 dependent L2 round trips: 27 us for the 8^3 x 32 output of the discriminators' last strided layer, and
+      // the same 28 us for the 29^3 one.]
+      constexpr int DEPTH = 16, NB = (NSTEP + DEPTH - 1) / DEPTH;
+      static_assert(NSTEP == NTAP, "one k-step per tap");
+      const int cols32 = p.cols * PITCH, plane32 = plane * PITCH;
+      const u16 *wl = p.w + (nt * 16 + m) * CI + 8 * kq;   // + tap * CO * CI   (C_out a multiple of 16: no padded column)
+      uint4 bq[2][DEPTH];
+      auto load_b = [&](uint4 (&dst)[DEPTH], int s0) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+          const int tap = p.flip ? NTAP - 1 - (s0 + i) : s0 + i;
+          if (s0 + i < NSTEP) dst[i] = *reinterpret_cast<const uint4 *>(wl + tap * (CO * CI));
+        }
+      };
+      load_b(bq[0], 0);
+#pragma unroll
+      for (int bt = 0; bt < NB; ++bt) {
+        if (bt + 1 < NB) load_b(bq[(bt + 1) & 1], (bt + 1) * DEPTH);
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+          const int tap = bt * DEPTH + i;
+          if (tap >= NSTEP) continue;
+          const int dz = tap / (K * K), dy = (tap / K) % K, dx = tap % K;
+          const int off = dz * plane32 + dy * cols32 + dx * PITCH + 8 * kq;
+          const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(patch + b0 + off));
+          const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(patch + b1 + off));
+          const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[bt & 1][i]);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc1, 0, 0, 0);
+        }
+      }
+    } else
 #pragma unroll 4
     for (int s = 0; s < NSTEP; ++s) {
       bf16x8 bf;
