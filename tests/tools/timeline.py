@@ -6,7 +6,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from transfer_em_amd.cgan import EM2EM
 from transfer_em_amd import hip_ops as H
-m = EM2EM(132, "tl", checkpoint_root="/tmp/tl_ck")
+m = EM2EM(132, "tl", checkpoint_root="/tmp/tl_ck", precision=(sys.argv[1] if len(sys.argv) > 1 else "fp32"))
 x = torch.randn(1, 132, 132, 132, 1, device="cuda"); y = torch.randn(1, 132, 132, 132, 1, device="cuda")
 for _ in range(5):
     m.train_step(x, y)

@@ -178,18 +178,41 @@ class _CompiledStep:
         # LDS-bound kernels only steal CUs from the dependent chains; again in round 2 with GPU_MAX_HW_QUEUES=8, so
         # that no two streams share a hardware queue: 9.35 vs 8.52 ms/step) and HIP stream priorities for the
         # chains (17.9 ms/step).
-        # (round 3, rejected: only the LAST sweeps' kernel gradients on the discriminators' streams, idle by then -- 7.416 vs 7.418
-        # ms/step: two generator chains already fill the chip in that phase)
+        # (what did pay, end of round 3: the kernel gradients BEHIND the discriminators' work on the discriminators' streams -- below)
         # (also measured and rejected: starting the F chain a few layers behind the G chain so that one chain's
         # full-resolution layers meet the other's 27^3..60^3 layers -- 9.74-9.77 vs 9.73 ms/step)
         main += casts + [("record", "cast")] + [flips["g"]] + L_(f_g1) + [("record", "fake_y")] + L_(f_g3) + [("wait", "fake_x")] + L_(f_g2)
         third += [("wait", "inputs"), flips["f"], ("wait", "cast")] + L_(f_f1) + [("record", "fake_x")] + L_(f_f3) + [("wait", "fake_y")] + L_(f_f2)
-        main += [loss[3], loss[4]] + L_(b_g3, b_g2) + [("record", "d_fake_x")]
-        third += [loss[2], loss[5]] + L_(b_f3, b_f2) + [("record", "d_fake_y")]
-        main += [("wait", "adv_y" if side_split else "adv"), ("wait", "d_fake_y"), add_y] + L_(b_g1) + red["g"]
-        third += [("wait", "adv_x" if side_split else "adv"), ("wait", "d_fake_x"), add_x] + L_(b_f1) + red["f"] + [("record", "third_done")]
+        # Kernel gradients are off the dependent chain (nothing in the sweep reads them; every layer of every sweep has its own
+        # gradient tensor and slab set): with one stream per discriminator they run on THOSE streams, behind the discriminators'
+        # own work -- the discriminators end at ~2.8 of 4.2 ms (bf16) / 4.2 of 7.4 (fp32), and in the phase where only the two
+        # generator chains are left a chain is launch gaps (5-7 us in front of each of its ~50 dependent launches) and kernels
+        # that leave half the chip idle.  Each one waits for the input-gradient launch that produced its gradient; the chain
+        # joins them in front of its slab reduction.  bf16 4.15 -> 4.03 ms/step, fp32 7.42 -> 7.35 (TEM_BWW_TAIL: 0 = in the
+        # chain, 1 = the last sweep only: 4.07 / 7.42; on two MORE streams instead: 6.6 ms, six streams serialize).
+        tail_mode = int(os.environ.get("TEM_BWW_TAIL", "2")) if side_split else 0
+        tails = {}
+        def sweep(plan, tag, mode=1):
+            if tail_mode < mode:
+                return L_(plan)
+            on_main, on_side, cur, k = [("record", f"{tag}.e0")], [], f"{tag}.e0", 1
+            for l in plan.launches:
+                if ".bww." in l.name:
+                    on_side += [("wait", cur), l]
+                else:
+                    cur = f"{tag}.e{k}"; k += 1
+                    on_main += [l, ("record", cur)]
+            tails[tag] = on_side + [("record", f"{tag}.bww_done")]
+            return on_main
+        joins = lambda *tags: [("wait", f"{t}.bww_done") for t in tags if t in tails]
+        main += [loss[3], loss[4]] + sweep(b_g3, "g3", 2) + sweep(b_g2, "g2", 2) + [("record", "d_fake_x")]
+        third += [loss[2], loss[5]] + sweep(b_f3, "f3", 2) + sweep(b_f2, "f2", 2) + [("record", "d_fake_y")]
+        main += [("wait", "adv_y" if side_split else "adv"), ("wait", "d_fake_y"), add_y] + sweep(b_g1, "g1") + joins("g3", "g2", "g1") + red["g"]
+        third += [("wait", "adv_x" if side_split else "adv"), ("wait", "d_fake_x"), add_x] + sweep(b_f1, "f1") + joins("f3", "f2", "f1") + red["f"] + [("record", "third_done")]
         main += [("wait", "side_done"), ("wait", "third_done")]
-        self.lists = (main, side, third) + ((side2,) if side_split else ())
+        tail_g = [x for t in ("g3", "g2", "g1") for x in tails.get(t, [])]       # behind the lists' last records: the chains
+        tail_f = [x for t in ("f3", "f2", "f1") for x in tails.get(t, [])]       # wait for '<sweep>.bww_done' themselves
+        self.lists = (main, side + tail_g, third) + ((side2 + tail_f,) if side_split else ())
 
         # ---- optimizer (cgan.py:218-228); gradients are averaged over ranks by grad_scale
         ws = m.world_size
@@ -207,7 +230,7 @@ class _CompiledStep:
         # generator sweep; each bucket's Adam launches follow their collective on the same stream.  ("allreduce",
         # key) is a no-op for world_size 1, so single-GPU runs execute the identical kernel sequence.
         cut = lambda lst, name: lst[:next(i for i, it in enumerate(lst) if it == ("record", name))]
-        side_f = cut(side, "side_done") + [("allreduce", "d"), adam["dx"], adam["dy"], ("record", "side_done")]
+        side_f = cut(side, "side_done") + [("allreduce", "d"), adam["dx"], adam["dy"], ("record", "side_done")] + tail_g
         if m.exchange:
             third_f = list(third)
             main_f = main[:-2] + [("wait", "third_done"), ("allreduce", "g"), adam["g"], adam["f"], ("wait", "side_done"), tick]
