@@ -271,14 +271,15 @@ int run(Dev p, int N, int max_slabs, hipStream_t st, bool dry, int *nslab_out) {
   p.TY = TY; p.rows = (TY - 1) * S + K;
   p.nband = (p.OH + TY - 1) / TY;
   const int cols = N * p.nband;
-  // ~1 workgroup per CU: with the plane ring and the register prefetch a workgroup overlaps its own fetches, and every workgroup
-  // costs a slab (written here, read again by reduce_multi_k) -- bf16 step by workgroup budget: 512: 4.64 ms, 384: 4.47, 256: 4.38,
-  // 192: 4.34, 128: 4.49, 96: 4.77 (round 2, before the ring: 320 measured slower than 512)
+  // Workgroup budget.  With the plane ring and the register prefetch a workgroup overlaps its own fetches, and every workgroup costs a
+  // slab (written here, read again by reduce_multi_k); the budget counts WORKGROUPS -- a layer whose rows are split over NGRP row
+  // groups gets budget / NGRP slabs (the 32 -> 32 4x4x4 layer of the discriminators wrote 200 slabs of 262 KB per call, 52 MB
+  // against 4 MB of operands).  bf16 step by budget, kernel gradients still in the dependent chains: 512: 4.64 ms, 384: 4.47, 256:
+  // 4.38, 192: 4.34, 128: 4.49; since they run beside the chains (cgan.py) their CU-time and slab bytes count, not their latency:
+  // 128 for slabs above 32 KB, 256 below: 4.03 -> 3.97 ms (96: 4.09; 128 for all: 4.12; the 32 KB line at 16 / 64 KB: 4.02 / 4.20).
   constexpr int NGRP = (MT + MTG - 1) / MTG;
-  // (the budget counts WORKGROUPS: a layer whose rows are split over NGRP row groups gets 256 / NGRP slabs -- the 32 -> 32
-  // 4x4x4 layer of the discriminators wrote 200 slabs of 262 KB per call, 52 MB against 4 MB of operands: 4.35 -> 4.25 ms)
   const bool small_slab = NTAP * CI * CO * 4 <= tem_env_int("TEM_BWWH_SMALLKB", 32) * 1024;
-  const int want_knob = (small_slab ? tem_env_int("TEM_BWWH_SMALL", 256) : tem_env_int("TEM_BWWH_WANT", 256)) / NGRP;
+  const int want_knob = (small_slab ? tem_env_int("TEM_BWWH_SMALL", 256) : tem_env_int("TEM_BWWH_WANT", 128)) / NGRP;
   int want = max_slabs < want_knob ? max_slabs : want_knob;
   int zsegs = want / cols;
   if (zsegs < 1) zsegs = 1;

@@ -412,7 +412,11 @@ static int plan_bww(BDev &p, size_t *lds_bytes, int EE, double *cost) {
       for (int zs = 1; zs <= p.NTZ; ++zs) {
         const int zper = (p.NTZ + zs - 1) / zs, zsegs = (p.NTZ + zper - 1) / zper;
         if (zsegs != zs) continue;
-        const double t = std::ceil(cols * zsegs / 256.0) * (pro + zper * step);
+        // (rounds of 128 workgroups, not 256: since the kernel gradients left the dependent chains for the discriminators'
+        // streams what counts is their CU-time and their slab traffic, not their latency -- half the workgroups = half the
+        // prologues, Winograd-domain finishes and slab bytes (g.mid: 252 -> 126 slabs of 110 KB per call); fp32 step by this
+        // divisor: 256: 7.39 ms, 192: 7.36, 128: 7.29, 96: 7.30, 64: 7.49)
+        const double t = std::ceil(cols * zsegs / (double)tem_env_int("TEM_WBWW_CUS", 128)) * (pro + zper * step);
         if (t < best) {
           best = t; p.BY = by; p.BX = bx; p.nby = nby; p.nbx = nbx; p.zsegs = zsegs; p.zper = zper;
           p.E = E; p.PLC = plv * 2; p.subb = subb; p.slotb = slotb; p.ndma = ndma; *lds_bytes = (bytes + 15) & ~(size_t)15;
