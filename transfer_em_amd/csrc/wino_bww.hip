@@ -416,7 +416,9 @@ static int plan_bww(BDev &p, size_t *lds_bytes, int EE, double *cost) {
         // streams what counts is their CU-time and their slab traffic, not their latency -- half the workgroups = half the
         // prologues, Winograd-domain finishes and slab bytes (g.mid: 252 -> 126 slabs of 110 KB per call); fp32 step by this
         // divisor: 256: 7.39 ms, 192: 7.36, 128: 7.29, 96: 7.30, 64: 7.49)
-        const double t = std::ceil(cols * zsegs / (double)tem_env_int("TEM_WBWW_CUS", 128)) * (pro + zper * step);
+        // + the slabs' way to HBM and back (written here, read by reduce_multi_k) at ~2 KB per cycle for the whole chip
+        const double slab = (double)cols * zsegs * (27.0 * CI * CO * 4.0) * 2.0 / 2000.0 * (tem_env_int("TEM_WBWW_SLABW", 100) / 100.0);
+        const double t = std::ceil(cols * zsegs / (double)tem_env_int("TEM_WBWW_CUS", 128)) * (pro + zper * step) + slab;
         if (t < best) {
           best = t; p.BY = by; p.BX = bx; p.nby = nby; p.nbx = nbx; p.zsegs = zsegs; p.zper = zper;
           p.E = E; p.PLC = plv * 2; p.subb = subb; p.slotb = slotb; p.ndma = ndma; *lds_bytes = (bytes + 15) & ~(size_t)15;
