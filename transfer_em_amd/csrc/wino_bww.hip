@@ -412,13 +412,13 @@ static int plan_bww(BDev &p, size_t *lds_bytes, int EE, double *cost) {
       for (int zs = 1; zs <= p.NTZ; ++zs) {
         const int zper = (p.NTZ + zs - 1) / zs, zsegs = (p.NTZ + zper - 1) / zper;
         if (zsegs != zs) continue;
-        // (rounds of 128 workgroups, not 256: since the kernel gradients left the dependent chains for the discriminators'
-        // streams what counts is their CU-time and their slab traffic, not their latency -- half the workgroups = half the
-        // prologues, Winograd-domain finishes and slab bytes (g.mid: 252 -> 126 slabs of 110 KB per call); fp32 step by this
-        // divisor: 256: 7.39 ms, 192: 7.36, 128: 7.29, 96: 7.30, 64: 7.49)
-        // + the slabs' way to HBM and back (written here, read by reduce_multi_k) at ~2 KB per cycle for the whole chip
+        // + the slabs' way to HBM and back (written here, read by reduce_multi_k) at ~2 KB per cycle for the whole chip: g.mid 252 ->
+        // 216 slabs of 110 KB per call, 7.39 -> 7.32 ms/step.  [Rounds of 128 instead of 256 workgroups (half the prologues,
+        // Winograd-domain finishes and slab bytes; the kernel gradients run beside the dependent chains, so their CU-time counts, not
+        // their latency) measured 7.25 ms/step, but every such launch then leaves half the chip idle when it runs alone (g.bww.mid
+        // 56 -> 107 us stand-alone): not taken, TEM_WBWW_CUS in knob builds.]
         const double slab = (double)cols * zsegs * (27.0 * CI * CO * 4.0) * 2.0 / 2000.0 * (tem_env_int("TEM_WBWW_SLABW", 100) / 100.0);
-        const double t = std::ceil(cols * zsegs / (double)tem_env_int("TEM_WBWW_CUS", 128)) * (pro + zper * step) + slab;
+        const double t = std::ceil(cols * zsegs / (double)tem_env_int("TEM_WBWW_CUS", 256)) * (pro + zper * step) + slab;
         if (t < best) {
           best = t; p.BY = by; p.BX = bx; p.nby = nby; p.nbx = nbx; p.zsegs = zsegs; p.zper = zper;
           p.E = E; p.PLC = plv * 2; p.subb = subb; p.slotb = slotb; p.ndma = ndma; *lds_bytes = (bytes + 15) & ~(size_t)15;
