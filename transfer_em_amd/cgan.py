@@ -134,8 +134,13 @@ class _CompiledStep:
         backward += [add_y, add_x]
         for p in (b_g1, b_f1, w_dxr, w_dxf, w_dyr, w_dyf):
             backward += p.launches
-        red = {k: w.reduce_launches(k) for k, w in (("g", wg), ("f", wf), ("dx", wdx), ("dy", wdy))}
-        reduce_ = red["g"] + red["f"] + red["dx"] + red["dy"]
+        # the generators' slab sums in two parts: the first two sweeps' slabs (calls 0, 1) are summed beside the last sweep, the
+        # launch at the end of the chain reads only the last sweep's (call 2)
+        red = {k: w.reduce_launches(k) for k, w in (("dx", wdx), ("dy", wdy))}
+        red_early = {}
+        for k, w in (("g", wg), ("f", wf)):
+            red_early[k], red[k] = w.reduce_launches(k, split_call=2)
+        reduce_ = red_early["g"] + red_early["f"] + red["g"] + red["f"] + red["dx"] + red["dy"]
         # once per network and step: the kernel copies the input-gradient convolutions read (fp32: tap-reversed /
         # transposed theta_t; bf16: the two bf16 copies every convolution reads)
         flips = {k: (net.params.pack_bf16_launch(k + ".pack_bf16") if bf else net.params.flip_transpose_launch(k + ".flip_transpose"))
@@ -207,11 +212,14 @@ class _CompiledStep:
         joins = lambda *tags: [("wait", f"{t}.bww_done") for t in tags if t in tails]
         main += [loss[3], loss[4]] + sweep(b_g3, "g3", 2) + sweep(b_g2, "g2", 2) + [("record", "d_fake_x")]
         third += [loss[2], loss[5]] + sweep(b_f3, "f3", 2) + sweep(b_f2, "f2", 2) + [("record", "d_fake_y")]
-        main += [("wait", "adv_y" if side_split else "adv"), ("wait", "d_fake_y"), add_y] + sweep(b_g1, "g1") + joins("g3", "g2", "g1") + red["g"]
-        third += [("wait", "adv_x" if side_split else "adv"), ("wait", "d_fake_x"), add_x] + sweep(b_f1, "f1") + joins("f3", "f2", "f1") + red["f"] + [("record", "third_done")]
+        main += [("wait", "adv_y" if side_split else "adv"), ("wait", "d_fake_y"), add_y] + sweep(b_g1, "g1") + joins("g3", "g2", "g1") + (red_early["g"] if tail_mode < 2 else []) + red["g"]
+        third += [("wait", "adv_x" if side_split else "adv"), ("wait", "d_fake_x"), add_x] + sweep(b_f1, "f1") + joins("f3", "f2", "f1") + (red_early["f"] if tail_mode < 2 else []) + red["f"] + [("record", "third_done")]
         main += [("wait", "side_done"), ("wait", "third_done")]
-        tail_g = [x for t in ("g3", "g2", "g1") for x in tails.get(t, [])]       # behind the lists' last records: the chains
-        tail_f = [x for t in ("f3", "f2", "f1") for x in tails.get(t, [])]       # wait for '<sweep>.bww_done' themselves
+        tail_g = [x for t in ("g3", "g2") for x in tails.get(t, [])]             # behind the lists' last records: the chains
+        tail_f = [x for t in ("f3", "f2") for x in tails.get(t, [])]             # wait for '<sweep>.bww_done' themselves
+        if tail_mode >= 2:
+            tail_g += red_early["g"]; tail_f += red_early["f"]
+        tail_g += tails.get("g1", []); tail_f += tails.get("f1", [])
         self.lists = (main, side + tail_g, third) + ((side2 + tail_f,) if side_split else ())
 
         # ---- optimizer (cgan.py:218-228); gradients are averaged over ranks by grad_scale

@@ -22,6 +22,16 @@ __device__ __forceinline__ int64_t voff(const V5h &v, int64_t i) {
   return n * v.sN + z * v.sD + y * v.sH + x * v.sW + c;
 }
 
+// the same for tensors of fewer than 2^31 elements: 32-bit divisions (the loss kernels sit on the step's critical chain)
+__device__ __forceinline__ int64_t voff32(const V5h &v, uint32_t i) {
+  uint32_t r = i, c = 0;
+  if (v.C != 1) { c = r % (uint32_t)v.C; r /= (uint32_t)v.C; }
+  const uint32_t x = r % (uint32_t)v.W; r /= (uint32_t)v.W;
+  const uint32_t y = r % (uint32_t)v.H; r /= (uint32_t)v.H;
+  const uint32_t z = r % (uint32_t)v.D, n = r / (uint32_t)v.D;
+  return (int64_t)n * v.sN + (int64_t)z * v.sD + (int64_t)y * v.sH + (int64_t)x * v.sW + c;
+}
+
 __device__ __forceinline__ void block_accumulate(double s, double *losses, uint32_t mask, double scale) {
   __shared__ double part[4];
   s = wave_sum(s);
@@ -90,8 +100,9 @@ __global__ __launch_bounds__(256) void focal_match_h_k(V5h a, V5h b, float gamma
                                                        double loss_scale, V5h db, float grad_scale, int64_t total) {
   const float eps = 1e-7f, hi = 1.0f - 1e-7f;
   double s = 0.0;
+  const bool small = total < ((int64_t)1 << 31);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    float av = bf2f(a.ptr[voff(a, i)]), bv = bf2f(b.ptr[voff(b, i)]);
+    float av = bf2f(a.ptr[small ? voff32(a, (uint32_t)i) : voff(a, i)]), bv = bf2f(b.ptr[small ? voff32(b, (uint32_t)i) : voff(b, i)]);
     float diff = av - bv;
     float t = 1.f - fabsf(diff) * 0.5f;
     float tc = fminf(fmaxf(t, eps), hi);
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(256) void focal_match_h_k(V5h a, V5h b, float gamma
     if (db.ptr) {
       float dper = 0.5f * (-dmod * ce + mod * dce);
       float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-      db.ptr[voff(db, i)] = f2bf(grad_scale * dper * 0.5f * sg);
+      db.ptr[small ? voff32(db, (uint32_t)i) : voff(db, i)] = f2bf(grad_scale * dper * 0.5f * sg);
     }
   }
   block_accumulate(s, losses, mask, loss_scale);
@@ -190,7 +201,15 @@ extern "C" int tem_focal_match_bf16(const tem_view *a, const tem_view *b, float 
   V5h d{};
   if (db && db->ptr) { if (!same_extents(*b, *db)) return TEM_ESHAPE; d = dvh(*db); }
   const int64_t total = vtotal(*a);
-  unsigned g = grid_for(total); if (g > 1024) g = 1024;
+  // (grid balanced between the serialized fp64 atomics of the workgroups' ends and the load latency per loop iteration, as in
+  // tem_focal_match: 1024 workgroups took 36 us for the 60^3 cycle loss)
+  unsigned g = grid_for(total);
+  {
+    const int slots = __builtin_popcount(slot_mask) > 0 ? __builtin_popcount(slot_mask) : 1;
+    const double best = sqrt((double)total / 256.0 * 1300.0 / (12.0 * slots));
+    const unsigned cap = best < 64 ? 64u : (best > 1024 ? 1024u : (unsigned)best);
+    if (g > cap) g = cap;
+  }
   hipLaunchKernelGGL(focal_match_h_k, dim3(g), dim3(256), 0, (hipStream_t)stream, dvh(*a), dvh(*b), gamma, losses, slot_mask,
                      (double)loss_scale / (double)total, d, grad_scale / (float)total, total);
   TEM_CHECK_LAUNCH();

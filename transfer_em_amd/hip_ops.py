@@ -235,27 +235,48 @@ class GradWorkspace:
             off += n
         raise KeyError((layer, call))
 
-    def reduce_launches(self, prefix):
-        """ONE launch summing calls x slabs of every layer into the flat gradient vector."""
+    def reduce_launches(self, prefix, split_call=None):
+        """ONE launch summing calls x slabs of every layer into the flat gradient vector.
+
+        split_call=c: two launches instead, returned as (early, final): `early` sums the slabs of the calls < c of every layer
+        IN PLACE into the last of those rows, `final` sums that row and the rows of the calls >= c into the gradient vector --
+        the early part can run as soon as the first sweeps' kernel gradients are done (beside the last sweep), and the launch at
+        the end of the step reads only the last sweep's slabs.  (Slab rows of a layer are in call order: request().)"""
         lib = _lib.load()
         self.finalize()
-        items = []
+        early, items = [], []
         for layer, t in self.buf.items():
             n, nsl = t.shape[1], t.shape[0]
+            first = 0                               # first row the final launch reads
+            if split_call is not None:
+                calls = [c for c, _, _ in self.requests[layer]]
+                assert calls == sorted(calls), "slab rows must be in call order"
+                n_early = sum(k for c, k, _ in self.requests[layer] if c < split_call)
+                if 2 <= n_early < nsl:
+                    first = n_early - 1
+                    for o in range(0, n, 64):
+                        early.append((t.data_ptr() + 4 * o, n, n_early, min(64, n - o), t[first].data_ptr() + 4 * o))
+            base, rows = t[first].data_ptr(), nsl - first
             out = self.params.g(layer)
             row = self.flip_rows.get(layer)
             if row:                 # C_out == 1 layers computed in swapped form: slab row r holds tap (ntap-1-r)
                 assert row <= 32 and n % row == 0
                 for r in range(n // row):
-                    items.append((t.data_ptr() + 4 * r * row, n, nsl, row, out.data_ptr() + 4 * (n // row - 1 - r) * row))
+                    items.append((base + 4 * r * row, n, rows, row, out.data_ptr() + 4 * (n // row - 1 - r) * row))
                 continue
             for o in range(0, n, 64):
-                items.append((t.data_ptr() + 4 * o, n, nsl, min(64, n - o), out.data_ptr() + 4 * o))
-        arr = (_lib.tem_reduce_item * len(items))(*[_lib.tem_reduce_item(*it) for it in items])
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        table = host.to(self.params.theta.device)
-        return [Launch(lib.tem_reduce_slabs_multi, (table.data_ptr(), len(items), 1.0), f"{prefix}.reduce",
-                       [table, self], dict(kernel="reduce_multi_k"))]
+                items.append((base + 4 * o, n, rows, min(64, n - o), out.data_ptr() + 4 * o))
+
+        def launch(its, name):
+            arr = (_lib.tem_reduce_item * len(its))(*[_lib.tem_reduce_item(*it) for it in its])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            table = host.to(self.params.theta.device)
+            return [Launch(lib.tem_reduce_slabs_multi, (table.data_ptr(), len(its), 1.0), name,
+                           [table, self], dict(kernel="reduce_multi_k"))]
+        final = launch(items, f"{prefix}.reduce")
+        if split_call is None:
+            return final
+        return (launch(early, f"{prefix}.reduce_early") if early else []), final
 
 
 def bww_launch(name, in0, dout, ws, layer, call, k, s=1, p=0, *, is3d=True, in1=None, wino=True):
