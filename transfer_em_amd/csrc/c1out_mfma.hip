@@ -25,6 +25,7 @@ namespace c1out {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2f __attribute__((ext_vector_type(2)));
 
 struct Dev {
   const float *in;
@@ -47,7 +48,7 @@ constexpr int OOB = (int)0x80000000;
 
 template <int CI, bool FLIP>
 __global__ __launch_bounds__(256, 2) void c1out_mfma_k(Dev p) {
-  static_assert(CI == 16, "one 16-byte load per lane and voxel");
+  static_assert(CI == 16 || CI == 8, "one 16- or 8-byte load per lane and voxel");
   constexpr int KS = CI / 4;                          // k-steps; lane group kq owns channels KS kq .. KS kq + KS - 1
   extern __shared__ __attribute__((aligned(16))) float P_[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -90,8 +91,13 @@ __global__ __launch_bounds__(256, 2) void c1out_mfma_k(Dev p) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       const int off = (zin && goff[i] != OOB) ? goff[i] + iz * p.iD * 4 : OOB;
-      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
-      a[i][0] = __uint_as_float(q.x); a[i][1] = __uint_as_float(q.y); a[i][2] = __uint_as_float(q.z); a[i][3] = __uint_as_float(q.w);
+      if constexpr (KS == 4) {
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+        a[i][0] = __uint_as_float(q.x); a[i][1] = __uint_as_float(q.y); a[i][2] = __uint_as_float(q.z); a[i][3] = __uint_as_float(q.w);
+      } else {
+        const u32x2f q = __builtin_amdgcn_raw_buffer_load_b64(xrs, off, 0, 0);
+        a[i][0] = __uint_as_float(q.x); a[i][1] = __uint_as_float(q.y);
+      }
     }
   };
 
@@ -356,7 +362,9 @@ static int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   if (a->kd != 3 || a->kh != 3 || a->kw != 3 || a->sd != 1 || a->sh != 1 || a->sw != 1) return TEM_EUNSUPPORTED;
   if (a->pd != a->ph || a->ph != a->pw) return TEM_EUNSUPPORTED;
   if (a->ep.dropout || a->ep.add.ptr) return TEM_EUNSUPPORTED;
-  if (i0.C != 16) return TEM_EUNSUPPORTED;          // (8 -> 1, the input-gradients of the first convolutions: measured slower than c1_stencil_k, 51 vs 38 us)
+  // (8 -> 1, the input-gradients of the first convolutions: compiled, but slower than c1_stencil_k -- 51 vs 38 us in round 2, 22.5
+  // vs 20.2 now: with half the MFMAs the kernel is bound by its shifted sum through LDS, as the bf16 variant is; knob builds only)
+  if (i0.C != 16 && !(i0.C == 8 && tem_env_int("TEM_C1OUT_8", 0))) return TEM_EUNSUPPORTED;
   static int enabled = -1;
   if (enabled < 0) enabled = tem_env_int("TEM_C1OUT_MFMA", 1);
   if (!enabled) return TEM_EUNSUPPORTED;
@@ -382,6 +390,7 @@ static int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   const bool flip = a->w_layout == TEM_W_FLIP_CO_CI;
   if (a->w_layout != TEM_W_TAP_CI_CO && !flip) return TEM_EUNSUPPORTED;
   const int N = i0.N;
+  if (i0.C == 8) return flip ? run<8, true>(p, N, st, dry) : run<8, false>(p, N, st, dry);   // input-gradients of the first convolutions
   return flip ? run<16, true>(p, N, st, dry) : run<16, false>(p, N, st, dry);     // g.f2 forward
 }
 
