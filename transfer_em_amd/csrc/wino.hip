@@ -471,6 +471,7 @@ int plan(Dev &p, double *cost, size_t *lds_bytes, int EE) {
                                  : (size_t)(PAIR ? 4 : 3) * NH * NB * 16 * 64 * 2 * 4;
   const int TY = (p.OH + 1) / 2, TX = (p.OW + 1) / 2;
   double best = 1e300;
+  static const int knob_cus = tem_env_int("TEM_WINO_CUS", 256), knob_cuw = tem_env_int("TEM_WINO_CUW", 400);
   for (int by = 1; by <= TY && by <= 64; ++by)
     for (int bx = 1; bx <= TX && bx <= 64; ++bx) {
       const int nt = by * bx;
@@ -493,7 +494,12 @@ int plan(Dev &p, double *cost, size_t *lds_bytes, int EE) {
       for (int zs = 1; zs <= p.NTZ; ++zs) {
         const int zper = (p.NTZ + zs - 1) / zs, zsegs = (p.NTZ + zper - 1) / zper;
         if (zsegs != zs) continue;
-        const double t = std::ceil(cols * zsegs / 256.0) * (pro + zper * step);
+        // latency of the launch alone (rounds of 256 workgroups) + 4 x its CU-time share: the step runs four streams that end
+        // together (cgan.py), so a launch's CU-time is what it costs -- a plan with fewer, longer z-runs pays fewer prologues
+        // (four planes + U: ~1.2 steps) even where it leaves CUs idle when the launch is timed alone.  fp32 step by this weight
+        // (with 3 x in wino_bww_k): 0: 7.24 ms, 0.5: 7.11, 1.5: 7.06, 4: 7.02, 10: 7.05; the dominant launch alone 79.9 -> 84 us.
+        const double t = std::ceil(cols * zsegs / (double)knob_cus) * (pro + zper * step) +
+                         knob_cuw / 100.0 * (cols * zsegs / 256.0) * (pro + zper * step);
         if (t < best) {
           best = t; p.BY = by; p.BX = bx; p.nby = nby; p.nbx = nbx; p.zsegs = zsegs; p.zper = zper;
           p.E = E; p.PLC = plv * 2; p.subb = subb; p.slotb = slotb; p.ndma = ndma; *lds_bytes = (bytes + 15) & ~(size_t)15;

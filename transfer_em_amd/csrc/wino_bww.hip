@@ -394,6 +394,8 @@ static int plan_bww(BDev &p, size_t *lds_bytes, int EE, double *cost) {
   constexpr int CIH = CI >= 16 ? CI / 16 : 1, NB = CO / 16 > 0 ? CO / 16 : 1, NC = CIH * NB, TB = CI == 32 ? 32 : 64;
   const int TY = (p.OH + 1) / 2, TX = (p.OW + 1) / 2;
   double best = 1e300;
+  static const int knob_cus = tem_env_int("TEM_WBWW_CUS", 256), knob_slabw = tem_env_int("TEM_WBWW_SLABW", 100),
+                   knob_cuw = tem_env_int("TEM_WBWW_CUW", 300);     // CU-time term as in wino.hip plan()
   for (int by = 1; by <= TY && by <= 64; ++by)
     for (int bx = 1; bx <= TX && bx <= 64; ++bx) {
       const int nt = by * bx;
@@ -417,8 +419,9 @@ static int plan_bww(BDev &p, size_t *lds_bytes, int EE, double *cost) {
         // Winograd-domain finishes and slab bytes; the kernel gradients run beside the dependent chains, so their CU-time counts, not
         // their latency) measured 7.25 ms/step, but every such launch then leaves half the chip idle when it runs alone (g.bww.mid
         // 56 -> 107 us stand-alone): not taken, TEM_WBWW_CUS in knob builds.]
-        const double slab = (double)cols * zsegs * (27.0 * CI * CO * 4.0) * 2.0 / 2000.0 * (tem_env_int("TEM_WBWW_SLABW", 100) / 100.0);
-        const double t = std::ceil(cols * zsegs / (double)tem_env_int("TEM_WBWW_CUS", 256)) * (pro + zper * step) + slab;
+        const double slab = (double)cols * zsegs * (27.0 * CI * CO * 4.0) * 2.0 / 2000.0 * (knob_slabw / 100.0);
+        const double t = std::ceil(cols * zsegs / (double)knob_cus) * (pro + zper * step) + slab +
+                         knob_cuw / 100.0 * (cols * zsegs / 256.0) * (pro + zper * step);
         if (t < best) {
           best = t; p.BY = by; p.BX = bx; p.nby = nby; p.nbx = nbx; p.zsegs = zsegs; p.zper = zper;
           p.E = E; p.PLC = plv * 2; p.subb = subb; p.slotb = slotb; p.ndma = ndma; *lds_bytes = (bytes + 15) & ~(size_t)15;
