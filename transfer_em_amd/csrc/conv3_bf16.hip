@@ -393,7 +393,7 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
   // output column (TX x TY) and z segments: fewest rounds of (march length + ring prologue) x tile pairs per wave
   double best = 1e30;
   const int knob_ty = tem_env_int("TEM_C3B_TY", 0), knob_nbx = tem_env_int("TEM_C3B_NBX", 0), knob_zs = tem_env_int("TEM_C3B_ZSEGS", 0);
-  const int knob_rd = tem_env_int("TEM_C3B_RD", 0);
+  const int knob_rd = tem_env_int("TEM_C3B_RD", 0), knob_cuw = tem_env_int("TEM_C3B_CUW", 300);   // CU-time term as in wino.hip plan(): bf16 step 3.89 -> 3.75 ms (1 x: 3.79, 10 x: 3.79)
   for (int nbx = 1; nbx <= 4; ++nbx) {
     if (knob_nbx && nbx != knob_nbx) continue;
     const int TX = (p.OW + nbx - 1) / nbx;
@@ -421,7 +421,7 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
           if (zs != zsegs) continue;
           const int64_t wgs = (int64_t)cols * zs;
           const double rounds = (double)((wgs + 255) / 256);
-          const double cost = rounds * ((zper + (K - S) / (double)S) * step + 7000.0);
+          const double cost = (rounds + knob_cuw / 100.0 * (double)wgs / 256.0) * ((zper + (K - S) / (double)S) * step + 7000.0);
           if (cost < best) {
             best = cost;
             p.TX = TX; p.TY = TY; p.nbx = nbx; p.nby = nby; p.zsegs = zs; p.zper = zper;
