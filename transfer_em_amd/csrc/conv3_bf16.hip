@@ -392,6 +392,15 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
   constexpr int NSTEP = (K * K * K * CI + 31) / 32, CPV = CI / 8, MAXJ = 40, NPG = SPLIT ? NW / ((CO + 15) / 16) : NW;
   // output column (TX x TY) and z segments: fewest rounds of (march length + ring prologue) x tile pairs per wave
   double best = 1e30;
+  struct Plan { double best; int TX, TY, nbx, nby, zsegs, zper, RW, PV, ndma, slot_bytes, RD, ndma_cnt; };
+  static tem_plan_cache<5, Plan> cache;                     // (the search below costs 5-30 us of host time per launch)
+  const std::array<int, 5> key{N, p.OD, p.OH, p.OW, p.in1 != p.in0 ? 1 : 0};
+  Plan memo;
+  if (cache.get(key, memo)) {
+    best = memo.best;
+    p.TX = memo.TX; p.TY = memo.TY; p.nbx = memo.nbx; p.nby = memo.nby; p.zsegs = memo.zsegs; p.zper = memo.zper; p.RW = memo.RW;
+    p.PV = memo.PV; p.ndma = memo.ndma; p.slot_bytes = memo.slot_bytes; p.RD = memo.RD; p.ndma_cnt = memo.ndma_cnt;
+  } else {
   const int knob_ty = tem_env_int("TEM_C3B_TY", 0), knob_nbx = tem_env_int("TEM_C3B_NBX", 0), knob_zs = tem_env_int("TEM_C3B_ZSEGS", 0);
   const int knob_rd = tem_env_int("TEM_C3B_RD", 0), knob_cuw = tem_env_int("TEM_C3B_CUW", 300);   // CU-time term as in wino.hip plan(): bf16 step 3.89 -> 3.75 ms (1 x: 3.79, 10 x: 3.79)
   for (int nbx = 1; nbx <= 4; ++nbx) {
@@ -431,6 +440,9 @@ static int run(Dev p, int N, hipStream_t st, bool dry, char *name, int name_len)
         }
       }
     }
+  }
+  memo = Plan{best, p.TX, p.TY, p.nbx, p.nby, p.zsegs, p.zper, p.RW, p.PV, p.ndma, p.slot_bytes, p.RD, p.ndma_cnt};
+  cache.put(key, memo);
   }
   if (best >= 1e30) return TEM_EUNSUPPORTED;
   p.dbg = tem_env_int("TEM_C3B_DBG", 0);

@@ -172,3 +172,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// Host-side memo of launch plans.  The planners of the z-marching kernels search a few thousand (tile, z-run) candidates per
+// call -- 10-50 us of host time per launch (1.7 of the 2.8 ms the launching thread spent per fp32 step, tests/tools/
+// host_per_launch.py) for a result that depends on the geometry alone.
+#include <array>
+#include <map>
+#include <mutex>
+template <size_t NK, typename R> struct tem_plan_cache {
+  std::mutex mu;
+  std::map<std::array<int, NK>, R> m;
+  bool get(const std::array<int, NK> &k, R &r) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = m.find(k);
+    if (it == m.end()) return false;
+    r = it->second;
+    return true;
+  }
+  void put(const std::array<int, NK> &k, const R &r) {
+    std::lock_guard<std::mutex> g(mu);
+    if (m.size() < 4096) m[k] = r;
+  }
+};

@@ -510,6 +510,26 @@ int plan(Dev &p, double *cost, size_t *lds_bytes, int EE) {
   return best < 1e300 ? TEM_OK : TEM_EUNSUPPORTED;
 }
 
+template <int CI, int CO, int NI>
+int plan_memo(Dev &p, double *cost, size_t *lds_bytes, int EE) {
+  struct R { int rc, BY, BX, nby, nbx, zsegs, zper, E, PLC, subb, slotb, ndma; size_t lds; double cost; };
+  static tem_plan_cache<5, R> cache;
+  const std::array<int, 5> key{p.N, p.OH, p.OW, p.NTZ, EE};
+  R r;
+  if (!cache.get(key, r)) {
+    r.lds = 0; r.cost = 1e300;
+    r.rc = plan<CI, CO, NI>(p, &r.cost, &r.lds, EE);
+    r.BY = p.BY; r.BX = p.BX; r.nby = p.nby; r.nbx = p.nbx; r.zsegs = p.zsegs; r.zper = p.zper; r.E = p.E; r.PLC = p.PLC;
+    r.subb = p.subb; r.slotb = p.slotb; r.ndma = p.ndma;
+    cache.put(key, r);
+  } else {
+    p.BY = r.BY; p.BX = r.BX; p.nby = r.nby; p.nbx = r.nbx; p.zsegs = r.zsegs; p.zper = r.zper; p.E = r.E; p.PLC = r.PLC;
+    p.subb = r.subb; p.slotb = r.slotb; p.ndma = r.ndma;
+  }
+  *cost = r.cost; *lds_bytes = r.lds;
+  return r.rc;
+}
+
 template <int CI, int CO, int NI, int EP, int EE>
 static int launch(const Dev &p, size_t lds_bytes, hipStream_t st) {
   const int nblocks = p.N * p.nby * p.nbx * p.zsegs;
@@ -539,7 +559,7 @@ int run_best(Dev p, hipStream_t st, bool dry) {
     Dev q = p;
     double c = 1e300;
     size_t l = 0;
-    if (plan<CI, CO, NI>(q, &c, &l, pitches[i]) == TEM_OK && c < cbest) { best = q; cbest = c; lds_bytes = l; }
+    if (plan_memo<CI, CO, NI>(q, &c, &l, pitches[i]) == TEM_OK && c < cbest) { best = q; cbest = c; lds_bytes = l; }
   }
   if (cbest >= 1e300) return TEM_EUNSUPPORTED;
   p = best;

@@ -432,6 +432,26 @@ static int plan_bww(BDev &p, size_t *lds_bytes, int EE, double *cost) {
   return best < 1e300 ? TEM_OK : TEM_EUNSUPPORTED;
 }
 
+template <int CI, int CO, int NI>
+static int plan_bww_memo(BDev &p, size_t *lds_bytes, int EE, double *cost) {
+  struct R { int rc, BY, BX, nby, nbx, zsegs, zper, E, PLC, subb, slotb, ndma; size_t lds; double cost; };
+  static tem_plan_cache<5, R> cache;
+  const std::array<int, 5> key{p.N, p.OH, p.OW, p.NTZ, EE};
+  R r;
+  if (!cache.get(key, r)) {
+    r.lds = 0; r.cost = 1e300;
+    r.rc = plan_bww<CI, CO, NI>(p, &r.lds, EE, &r.cost);
+    r.BY = p.BY; r.BX = p.BX; r.nby = p.nby; r.nbx = p.nbx; r.zsegs = p.zsegs; r.zper = p.zper; r.E = p.E; r.PLC = p.PLC;
+    r.subb = p.subb; r.slotb = p.slotb; r.ndma = p.ndma;
+    cache.put(key, r);
+  } else {
+    p.BY = r.BY; p.BX = r.BX; p.nby = r.nby; p.nbx = r.nbx; p.zsegs = r.zsegs; p.zper = r.zper; p.E = r.E; p.PLC = r.PLC;
+    p.subb = r.subb; p.slotb = r.slotb; p.ndma = r.ndma;
+  }
+  *cost = r.cost; *lds_bytes = r.lds;
+  return r.rc;
+}
+
 // mode 0: launch; 1: slab-count query (*nslab); 2: describe
 static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, char *name, int name_len) {
   const tem_view &i0 = a->in0, &dy = a->dout;
@@ -483,9 +503,9 @@ static int run_bww(const tem_bww_args *a, hipStream_t st, int mode, int *nslab, 
       BDev q = p;
       double c = 1e300;
       size_t l = 0;
-      const int r = variant == 0 ? plan_bww<8, 8, 2>(q, &l, EE, &c) : variant == 1 ? plan_bww<16, 16, 2>(q, &l, EE, &c)
-                  : variant == 2 ? plan_bww<8, 16, 2>(q, &l, EE, &c) : variant == 3 ? plan_bww<16, 32, 2>(q, &l, EE, &c)
-                  : variant == 4 ? plan_bww<32, 16, 2>(q, &l, EE, &c) : plan_bww<32, 32, 2>(q, &l, EE, &c);
+      const int r = variant == 0 ? plan_bww_memo<8, 8, 2>(q, &l, EE, &c) : variant == 1 ? plan_bww_memo<16, 16, 2>(q, &l, EE, &c)
+                  : variant == 2 ? plan_bww_memo<8, 16, 2>(q, &l, EE, &c) : variant == 3 ? plan_bww_memo<16, 32, 2>(q, &l, EE, &c)
+                  : variant == 4 ? plan_bww_memo<32, 16, 2>(q, &l, EE, &c) : plan_bww_memo<32, 32, 2>(q, &l, EE, &c);
       if (r == TEM_OK && c < cbest) { best = q; cbest = c; lds_bytes = l; rc = TEM_OK; }
     }
     p = best;
