@@ -71,9 +71,15 @@ def per_kernel_profile(model, st, steps, streams=True):
         torch.cuda.synchronize()
         for l, a, b in evs:
             k = l.meta.get("kernel", l.name.split(".")[0] + ".misc")
-            d = agg.setdefault(k, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
-            d["ms"] += a.elapsed_time(b); d["launches"] += 1
+            d = agg.setdefault(k, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, big_bytes=0.0, big_ms=0.0, big_n=0))
+            t = a.elapsed_time(b)
+            d["ms"] += t; d["launches"] += 1
             d["flops"] += l.meta.get("flops", 0.0); d["bytes"] += l.meta.get("bytes", 0.0)
+            by = l.meta.get("bytes", 0.0)              # the symbol's LARGEST launches (full-size layers, not the cone windows)
+            if by > d["big_bytes"]:
+                d["big_bytes"], d["big_ms"], d["big_n"] = by, 0.0, 0
+            if by == d["big_bytes"] and by > 0:
+                d["big_ms"] += t; d["big_n"] += 1
     return agg
 
 
@@ -313,6 +319,10 @@ def main():
                                          "best": {"kernel": kmax, "gbs": hb[kmax], "frac": hb[kmax] / HBM_PEAK_GBS,
                                                   "frac_of_measured_copy": hb[kmax] / HBM_COPY_GBS},
                                          "all": {k: round(g, 1) for k, g in sorted(hb.items(), key=lambda kv: kv[1])},
+                                         # the same for each symbol's largest launches only (the averages above include the
+                                         # cycle path's cone windows, whose small grids cannot fill the chip)
+                                         "full_size": {k: round(agg[k]["big_bytes"] * agg[k]["big_n"] / (agg[k]["big_ms"] * 1e-3) / 1e9, 1)
+                                                       for k in sorted(hb, key=hb.get) if agg[k]["big_ms"] > 0},
                                          "traffic_ratio": {k: round(traffic[k]["hbm_bytes_per_launch"] * agg[k]["launches"] / agg[k]["bytes"], 3)
                                                            for k in hb if k in traffic}}
         if args.kernel_table:

@@ -176,7 +176,7 @@ def test_transposed_convolution_step_shapes(H, T, oracle_lib, layer, CI, CO, n):
 # (layer, CI, CO, input edge, pad, flip = input-gradient form, gated, expected kernel prefix)
 C1 = [("g.c0", 1, 8, 132, 0, False, False, "c1_mfma_k<8"), ("d.d1a", 1, 8, 96, 0, False, False, "c1_mfma_k<8"),
       ("g.bd.f2", 1, 16, 96, 2, True, True, "c1_mfma_k<16"), ("g.f2", 16, 1, 98, 0, False, False, "c1out_mfma_k"),
-      ("g.bd.c0 window", 8, 1, 130, -16, True, False, "c1_stencil_k"), ("d.bd.d1a", 8, 1, 94, 2, True, False, "c1_stencil_k")]
+      ("g.bd.c0 window", 8, 1, 130, -16, True, False, "c1out_mfma_k<8"), ("d.bd.d1a", 8, 1, 94, 2, True, False, "c1out_mfma_k<8")]
 
 
 @pytest.mark.parametrize("layer,CI,CO,n,pad,flip,gated,kernel", C1)

@@ -389,9 +389,9 @@ static int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
   if (a->kd != 3 || a->kh != 3 || a->kw != 3 || a->sd != 1 || a->sh != 1 || a->sw != 1) return TEM_EUNSUPPORTED;
   if (a->pd != a->ph || a->ph != a->pw) return TEM_EUNSUPPORTED;
   if (a->ep.dropout || a->ep.add.ptr) return TEM_EUNSUPPORTED;
-  // (8 -> 1, the input-gradients of the first convolutions: compiled, but slower than c1_stencil_k -- 51 vs 38 us in round 2, 22.5
-  // vs 20.2 now: with half the MFMAs the kernel is bound by its shifted sum through LDS, as the bf16 variant is; knob builds only)
-  if (i0.C != 16 && !(i0.C == 8 && tem_env_int("TEM_C1OUT_8", 0))) return TEM_EUNSUPPORTED;
+  // (8 -> 1, the input-gradients of the first convolutions: slower than c1_stencil_k until the kernel's instruction diet -- 51 vs 38 us
+  // in round 2, 22.5 vs 20.2 before it, 18.7 vs 20.2-22 after; TEM_C1OUT_8=0 in knob builds selects the stencil)
+  if (i0.C != 16 && !(i0.C == 8 && tem_env_int("TEM_C1OUT_8", 1))) return TEM_EUNSUPPORTED;
   static int enabled = -1;
   if (enabled < 0) enabled = tem_env_int("TEM_C1OUT_MFMA", 1);
   if (!enabled) return TEM_EUNSUPPORTED;
