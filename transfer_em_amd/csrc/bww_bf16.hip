@@ -176,11 +176,17 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
   };
   // prologue: the K planes and the G rows of the first output plane
   {
-    xchunk pf[PF1];
+    // (all K planes and the G rows requested before the first LDS write: plane by plane -- issue, wait, write -- the prologue of
+    // every workgroup was K + 1 serialized memory round trips, tests/tools/isa_serial_loads.py)
+    xchunk pf[K][PF1];
     uint4 pg[PFG];
     __syncthreads();                                         // zero fill done
-    for (int c = 0; c < K; ++c) { issue_x(c, pf); commit_x(c, pf); }
-    issue_g(oz0, pg); commit_g(pg);
+#pragma unroll
+    for (int c = 0; c < K; ++c) issue_x(c, pf[c]);
+    issue_g(oz0, pg);
+#pragma unroll
+    for (int c = 0; c < K; ++c) commit_x(c, pf[c]);
+    commit_g(pg);
   }
   for (int oz = oz0; oz < oz1; ++oz) {
     __syncthreads();                                         // this plane's image is complete

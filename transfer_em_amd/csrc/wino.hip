@@ -180,10 +180,17 @@ __global__ __launch_bounds__(512) void wino_conv_k(Dev p) {
   if (STREAM) {
     dma_u(0, 0);
   } else {
+    // (LDS-DMA like the planes: as a copy loop through registers hipcc emitted load -> s_waitcnt vmcnt(0) -> ds_write per
+    // iteration -- 3 to 12 serialized memory round trips, each also waiting for the planes' DMA, in EVERY workgroup's prologue)
     constexpr int UF4 = NKZ * NH * NB * 16 * 64 * 2 / 4;
-    const float4 *us = reinterpret_cast<const float4 *>(p.u);
-    float4 *ud = reinterpret_cast<float4 *>(uld);
-    for (int i = tid; i < UF4; i += 512) ud[i] = us[i];
+    static_assert(UF4 % 512 == 0, "whole 1 KB wave transfers");
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, UF4 * 16, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < UF4 / 512; ++i) {
+      const int j = wave + 8 * i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void *)((char *)uld + j * 1024), 16,
+                                               (j * 64 + lane) * 16, 0, 0, 0);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prologue's planes (inline-assembly DMA: no wait of the compiler's)
   __syncthreads();
