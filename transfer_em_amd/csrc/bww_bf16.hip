@@ -45,14 +45,18 @@ struct Dev {
 template <int CI, int CO, int K, int S, int PFX, int PFG, int MTG>
 __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
   constexpr int NTAP = K * K * K, ROWS = NTAP * CI, MT = (ROWS + 15) / 16, NT = (CO + 15) / 16;
-  constexpr int WPN = 4 / NT;                              // waves per n-tile
-  constexpr int TPW = (MTG + WPN - 1) / WPN;               // accumulator tiles per wave
+  // C_out = 32 (two n-tiles): a wave multiplies each of its A fragments with BOTH n-tiles' B fragments -- 2 + TPW LDS reads per
+  // 2 TPW MFMAs instead of 1 + 2 TPW (the transposing reads, not the matrix cores, set the kernel's pace); the four waves split the
+  // m-tiles.  C_out <= 16: one n-tile, WPN = 4 waves on it.
+  constexpr int NB = NT;                                   // n-tiles per wave
+  constexpr int WPN = 4;                                   // waves per m-tile group
+  constexpr int TPW = (MTG + WPN - 1) / WPN;               // m-tiles per wave (x NB accumulator tiles)
   // voxel pitches (bf16 elements): measured (tests/tools/lds_tr_probe.hip) the transposing read streams 171 B/clk/CU at voxel
   // pitches up to 32 bytes and 117 beyond -- the 8-byte pad of round 2 (40 bytes at 16 channels) cost a third of the rate
   constexpr int PITCH = CI >= 8 ? (CI <= 16 ? CI : CI + 4) : 1;
   constexpr int GP = CO <= 16 ? CO : CO + 4;
   constexpr int CPX = CI >= 8 ? CI / 8 : 1, CPG = CO / 8;  // 16-byte chunks per voxel
-  static_assert(CO % 8 == 0 && (CI == 1 || CI % 8 == 0) && 4 % NT == 0, "channel counts");
+  static_assert(CO % 8 == 0 && (CI == 1 || CI % 8 == 0) && NT <= 2, "channel counts");
   extern __shared__ __attribute__((aligned(16))) u16 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,13 +78,12 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
   // zero the whole image once: padded columns / voxels are never written again and must stay zero (G) / finite (X)
   for (int i = tid; i < (x_elems + g_elems + 7) / 8; i += 256) reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
 
-  // ---- this wave's accumulator tiles: n-tile fixed, m-tiles grp*MTG + (wave/NT) + j*WPN
-  const int nt = wave % NT;
+  // ---- this wave's accumulator tiles: m-tiles grp*MTG + wave + j*WPN, all n-tiles
   int aconst[TPW], adz[TPW];                               // fragment offset inside a plane, z tap of the lane's rows
-  f32x4 acc[TPW];
+  f32x4 acc[TPW][NB];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
-    const int mt = min(grp * MTG + wave / NT + j * WPN, MT - 1);       // surplus tiles recompute the last one, never stored
+    const int mt = min(grp * MTG + wave + j * WPN, MT - 1);            // surplus tiles recompute the last one, never stored
     if constexpr (CI >= 8) {
       const int m0 = min(16 * mt + 4 * pq, ROWS - 4);                   // this lane addresses rows m0..m0+3 (4 channels of one tap)
       const int tap = m0 / CI, ci0 = m0 - tap * CI;
@@ -93,9 +96,12 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
       adz[j] = dz;
       aconst[j] = dy * p.colsA + dx + 4 * g4;
     }
-    acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[j][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int bconst = (4 * g4 + q) * GP + min(nt * 16 + 4 * pq, CO + 4 - 4);
+  int bconst[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bconst[nb] = (4 * g4 + q) * GP + min(nb * 16 + 4 * pq, CO + 4 - 4);
 
   const int iy0 = oy0 * S - p.P;
   const int nk = p.OWp >> 4;
@@ -209,9 +215,11 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
     // shuttles every accumulator between AGPRs and VGPRs per MFMA: 53 us)
     for (int r = 0; r < TYr; ++r) {
       const u16 *xr = Xs + r * S * p.colsA * PITCH;
-      const u16 *gr = Gs + r * p.OWp * GP + bconst;
+      const u16 *gr = Gs + r * p.OWp * GP;
       for (int kb = 0; kb < nk; ++kb) {
-        const s16x4 bfrag = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(gr + kb * 16 * GP));
+        s16x4 bfrag[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bfrag[nb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(gr + bconst[nb] + kb * 16 * GP));
         s16x4 afrag[TPW];
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
@@ -223,7 +231,9 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
           }
         }
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afrag[j], bfrag, acc[j], 0, 0, 0);
+        for (int j = 0; j < TPW; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afrag[j], bfrag[nb], acc[j][nb], 0, 0, 0);
       }
     }
     if (more) {
@@ -238,13 +248,16 @@ __global__ __launch_bounds__(256) void bww_bf16_k(Dev p) {
   float *slab = p.slabs + (int64_t)blockIdx.x * p.slab_stride;
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
-    const int mtl = wave / NT + j * WPN, mt = grp * MTG + mtl;
+    const int mtl = wave + j * WPN, mt = grp * MTG + mtl;
     if (mtl < MTG && mt < MT) {
-      const int co = nt * 16 + m;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + g4 * 4 + r;              // C/D map: row = 4*(lane>>4)+reg, col = lane&15
-        if (row < ROWS && co < CO) slab[(int64_t)row * CO + co] = acc[j][r];
+      for (int nb = 0; nb < NB; ++nb) {
+        const int co = nb * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mt * 16 + g4 * 4 + r;            // C/D map: row = 4*(lane>>4)+reg, col = lane&15
+          if (row < ROWS && co < CO) slab[(int64_t)row * CO + co] = acc[j][nb][r];
+        }
       }
     }
   }
