@@ -61,7 +61,10 @@ struct Dev {
 
 // NCLS: (r_z, r_y) classes handled per workgroup on ONE loaded patch (their B fragments all stay in registers:
 // NCLS * 2 C_in VGPRs) -- 4 for C_in 8, 2 (both r_y of one r_z) for C_in 16, 1 for C_in 32
-template <int CI, int CO, int PF, int NCLS>
+// EPM: compiled epilogue as in convT_mfma_k -- 0: run-time flags; 1: forward of the train step (keep bits drawn ahead, LeakyReLU; no
+// gate / skip-gradient); 2: input-gradient (gate, optional skip-gradient add, no Dropout).  [With run-time flags a tile iteration
+// was ~800 instructions for 4..16 MFMAs.]
+template <int CI, int CO, int PF, int NCLS, int EPM>
 __global__ __launch_bounds__(256) void convT_bf16_k(Dev p, const u16 *__restrict__ wgt) {
   constexpr int CIP = CI;                         // LDS voxel pitch (bf16 elements): the plain channels-last image (b128 fragment reads are conflict-free, lds_b128_probe; the 16-byte pad of round 2 cost ~8 %)
   constexpr int NT = 2 * CO / 16;                 // n-tiles over the columns (r_x, co)
@@ -175,20 +178,26 @@ __global__ __launch_bounds__(256) void convT_bf16_k(Dev p, const u16 *__restrict
     const int qy = p.nQx == 1 ? v : (int)__umulhi((uint32_t)v, p.magicQx), qx = v - qy * p.nQx;
     q.oy = 2 * (Qy0 + qy) + ry - p.P; q.ox = 2 * (p.Qlo_x + qx) + erx - p.P;
     q.valid = v < L && (unsigned)q.oy < (unsigned)p.OH && (unsigned)q.ox < (unsigned)p.OW;
-    int goff = q.valid ? (n * ep.gN + oz * ep.gD + q.oy * ep.gH + q.ox * ep.gW + eco) * 2 : (int)0x80000000;
-    asm volatile("" : "+v"(goff));
-    const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(grs, goff, 0, 0);
-    q.g4 = make_uint2(g.x, g.y);
-    const int az = oz - ep.aoz, ay = q.oy - ep.aoy, ax = q.ox - ep.aox;
-    const bool ain = q.valid && (unsigned)az < (unsigned)ep.aDd && (unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw;
-    int aoff = ain ? (n * ep.aN + az * ep.aD + ay * ep.aH + ax * ep.aW + eco) * 2 : (int)0x80000000;
-    asm volatile("" : "+v"(aoff));
-    const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(ars, aoff, 0, 0);
-    q.a4 = make_uint2(a.x, a.y);
-    const uint32_t e3 = (uint32_t)((((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (q.oy + ep.doy)) * ep.dW + (q.ox + ep.dox)) * (uint64_t)CO + eco) >> 3);
-    int moff = q.valid ? (int)e3 : (int)0x80000000;
-    asm volatile("" : "+v"(moff));
-    q.kb = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(mrs, moff, 0, 0);
+    q.g4 = make_uint2(0u, 0u); q.a4 = q.g4; q.kb = 0;
+    if (EPM != 1) {
+      int goff = q.valid ? (n * ep.gN + oz * ep.gD + q.oy * ep.gH + q.ox * ep.gW + eco) * 2 : (int)0x80000000;
+      asm volatile("" : "+v"(goff));
+      const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(grs, goff, 0, 0);
+      q.g4 = make_uint2(g.x, g.y);
+      const int az = oz - ep.aoz, ay = q.oy - ep.aoy, ax = q.ox - ep.aox;
+      const bool ain = q.valid && (unsigned)az < (unsigned)ep.aDd && (unsigned)ay < (unsigned)ep.aHh && (unsigned)ax < (unsigned)ep.aWw;
+      int aoff = ain ? (n * ep.aN + az * ep.aD + ay * ep.aH + ax * ep.aW + eco) * 2 : (int)0x80000000;
+      asm volatile("" : "+v"(aoff));
+      const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(ars, aoff, 0, 0);
+      q.a4 = make_uint2(a.x, a.y);
+    }
+    if (EPM != 2) {
+      // (the element count is below 2^32: host)
+      const uint32_t vox = (((uint32_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (q.oy + ep.doy)) * ep.dW + (q.ox + ep.dox);
+      int moff = q.valid ? (int)(vox * (uint32_t)(CO >> 3) + (uint32_t)(eco >> 3)) : (int)0x80000000;
+      asm volatile("" : "+v"(moff));
+      q.kb = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(mrs, moff, 0, 0);
+    }
     return q;
   };
   auto finish = [&](const f32x4 &acc, const Prep &q, int oz) {
@@ -200,18 +209,18 @@ __global__ __launch_bounds__(256) void convT_bf16_k(Dev p, const u16 *__restrict
     const bool valid = q.valid;
     float vv[4] = {v4.x + bf2f((u16)(q.a4.x & 0xffffu)), v4.y + bf2f((u16)(q.a4.x >> 16)),
                    v4.z + bf2f((u16)(q.a4.y & 0xffffu)), v4.w + bf2f((u16)(q.a4.y >> 16))};
-    if (ep.gate) {
+    if (EPM == 2 || (EPM == 0 && ep.gate)) {
       vv[0] = bf2f((u16)(q.g4.x & 0xffffu)) > 0.f ? vv[0] : ep.gate_slope * vv[0];
       vv[1] = bf2f((u16)(q.g4.x >> 16)) > 0.f ? vv[1] : ep.gate_slope * vv[1];
       vv[2] = bf2f((u16)(q.g4.y & 0xffffu)) > 0.f ? vv[2] : ep.gate_slope * vv[2];
       vv[3] = bf2f((u16)(q.g4.y >> 16)) > 0.f ? vv[3] : ep.gate_slope * vv[3];
     }
-    if (ep.dropout) {                                          // kernel-uniform
-      const uint64_t e = ((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint64_t)CO + eco;
+    if (EPM == 1 || (EPM == 0 && ep.dropout)) {                // kernel-uniform
       uint32_t bits;
-      if (ep.keep_mode == 2) {
-        bits = (q.kb >> (uint32_t)(e & 4u)) & 15u;              // (fetched by prep; zero for lanes without a voxel)
+      if (EPM == 1 || ep.keep_mode == 2) {
+        bits = (q.kb >> (uint32_t)(eco & 4)) & 15u;             // (fetched by prep; zero for lanes without a voxel)
       } else {
+        const uint64_t e = ((((uint64_t)n * ep.dD + (oz + ep.doz)) * ep.dH + (oy + ep.doy)) * ep.dW + (ox + ep.dox)) * (uint64_t)CO + eco;
         const Philox128 ph = ds.block(e >> 7);
         const uint32_t eb = (uint32_t)(e & 127);
         bits = 0;
@@ -276,7 +285,7 @@ static thread_local int g_name_len = 0;
 static int floordiv2(int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }
 
 template <int CI, int CO, int PF, int NCLS>
-int run(Dev p, int N, const u16 *w, hipStream_t st, bool dry) {
+int run(Dev p, int N, const u16 *w, hipStream_t st, bool dry, int epm) {
   constexpr int CIP = CI, CPV = CI / 8;
   // o + P = 2Q + r  =>  Q in [floor(P/2), floor((O-1+P)/2)]
   p.Qlo_x = floordiv2(p.P); p.nQx = floordiv2(p.OW - 1 + p.P) - p.Qlo_x + 1;
@@ -298,7 +307,7 @@ int run(Dev p, int N, const u16 *w, hipStream_t st, bool dry) {
   p.magicQx = magic_for(p.nQx);
   p.magicCols = magic_for(p.cols);
   if (dry) {
-    if (g_name) snprintf(g_name, g_name_len, "convT_bf16_k<%d, %d, %d, %d>", CI, CO, PF, NCLS);
+    if (g_name) snprintf(g_name, g_name_len, "convT_bf16_k<%d, %d, %d, %d, %d>", CI, CO, PF, NCLS, epm);
     return TEM_OK;
   }
   static int dbg = -1;
@@ -308,7 +317,9 @@ int run(Dev p, int N, const u16 *w, hipStream_t st, bool dry) {
   if (dbg & 8)
     fprintf(stderr, "convT_bf16<%d,%d> O=%dx%dx%d P=%d: nQ=%dx%dx%d TY=%d bands=%d blocks=%d lds=%zu\n", CI, CO, p.OD, p.OH,
             p.OW, p.P, p.nQz, p.nQy, p.nQx, p.TY, p.nband, nblocks, lds_bytes);
-  hipLaunchKernelGGL((convT_bf16_k<CI, CO, PF, NCLS>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
+  if (epm == 1) hipLaunchKernelGGL((convT_bf16_k<CI, CO, PF, NCLS, 1>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
+  else if (epm == 2) hipLaunchKernelGGL((convT_bf16_k<CI, CO, PF, NCLS, 2>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
+  else hipLaunchKernelGGL((convT_bf16_k<CI, CO, PF, NCLS, 0>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, p, w);
   TEM_CHECK_LAUNCH();
   return TEM_OK;
 }
@@ -373,7 +384,10 @@ int dispatch(const tem_conv_args *a, hipStream_t st, bool dry) {
     q.abytes = e.add.ptr ? (int)(span(e.add) * 2) : 0;
   }
   const int CI = i0.C, CO = o0.C, N = i0.N;
-#define CT_CASE(ci, co, pf, ncls) if (CI == ci && CO == co) return run<ci, co, pf, ncls>(p, N, U(a->w), st, dry);
+  int epm = 0;
+  if (p.ep.dropout && p.ep.keep_mode == 2 && !p.ep.gate && !p.ep.add) epm = 1;
+  else if (!p.ep.dropout && p.ep.gate) epm = 2;
+#define CT_CASE(ci, co, pf, ncls) if (CI == ci && CO == co) return run<ci, co, pf, ncls>(p, N, U(a->w), st, dry, epm);
   CT_CASE(16, 8, 12, 1)     // g.u1b forward (Conv3DTranspose 16 -> 8)
   CT_CASE(32, 16, 12, 1)    // g.u2b forward
   CT_CASE(8, 8, 12, 1)      // input-gradient of g.d1b / d.d1b    (more classes per patch measured no faster)

@@ -177,7 +177,7 @@ class GenForward:
                 self.keep[blk] = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
         # fp32 3-D: ONE small launch per call draws both layers' keep bits ahead of the transposed convolutions, which
         # then read them like the input-gradient kernels do (the Philox rounds cost g.u1b 10 of its 50 us)
-        premask = bool(self.keep) and is3d and not bf and not direct
+        premask = bool(self.keep) and is3d and not direct        # (bf16 too: convT_bf16_k reads the keep bits as convT_mfma_k does)
         km = lambda blk, mode: (self.keep[blk], 2 if (premask and mode == 1) else mode) if blk in self.keep else None
         kw = dict(is3d=is3d, direct=direct)
         pc = lambda p, s, i, o: p + lo(i) - s * lo(o) if i else p - s * lo(o)      # conv-like pad ('' = full input x)
