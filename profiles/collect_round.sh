@@ -29,7 +29,7 @@ cp $OUT/hbm_traffic.json $OUT/mfma_busy.json $ROOT/profiles/
 python3 $ROOT/bench.py --steps 100 --warmup 20 --kernel-table > $OUT/bench.json 2> $OUT/kernel_table.txt
 echo "bench fp32 done"
 # bf16 mixed precision (BASELINE configs[4], single-GPU share): bench line + kernel table + rocprof stats
-python3 $ROOT/bench.py --dtype bf16 --steps 20 --warmup 5 --kernel-table --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/kernel_table_bf16.txt
+python3 $ROOT/bench.py --dtype bf16 --steps 100 --warmup 20 --kernel-table --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/kernel_table_bf16.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bf16 -- python3 $ROOT/bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --single-stream > $OUT/bench_bf16_single_stream_under_rocprof.json 2> /dev/null
 echo "bf16 done"
 # the other single-GPU configurations (config 3's per-GPU workload, config 4)
