@@ -478,7 +478,10 @@ def wino_weights_launch(name, theta, u, table_dev, nlayers):
                   [theta, u, table_dev])
 
 
-WINO_MIN_VOXELS = int(os.environ.get("TEM_WINO_MIN_VOXELS", "27000"))
+# Smallest output volume that takes the Winograd kernels.  27,000 until the planners priced a launch's CU-time (csrc/wino.hip
+# plan()): below it a Winograd launch used to fill the chip with short z-runs and lost to conv_lds_k / bww_s2_k (7.59 vs 7.56
+# ms/step); planned for the step it wins down to ~20^3 (fp32 step by this threshold: 27000: 6.99 ms, 13000: 6.92, 8000: 6.84, 3000: 6.84).
+WINO_MIN_VOXELS = int(os.environ.get("TEM_WINO_MIN_VOXELS", "8000"))
 WINO_U_FLOATS = 6144          # floats of the Winograd-domain copy of one 3x3x3 kernel per 8 input and <= 16 output channels
 
 
