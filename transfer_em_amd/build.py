@@ -29,14 +29,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+FLAGS_STAMP = os.path.join(OBJ, ".flags")     # the flags the objects were built with: a knob build is never mistaken for the shipped one
+
+
+def _flags_changed():
+    try:
+        return open(FLAGS_STAMP).read() != " ".join(FLAGS)
+    except OSError:
+        return True
+
+
 def needs_build():
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    return _stale(OUT, srcs + _headers())
+    return _flags_changed() or _stale(OUT, srcs + _headers())
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
+    force = force or _flags_changed()
     os.makedirs(OBJ, exist_ok=True)
     hdrs = _headers()
     jobs = []
@@ -56,6 +67,8 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(" ".join(FLAGS))
     return OUT
 
 
