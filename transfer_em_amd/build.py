@@ -29,7 +29,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-FLAGS_STAMP = os.path.join(OBJ, ".flags")     # the flags the objects were built with: a knob build is never mistaken for the shipped one
+FLAGS_STAMP = os.path.join(HERE, "lib", ".build_flags")     # the flags the objects were built with: a knob build is never mistaken for the shipped one
 
 
 def _flags_changed():
